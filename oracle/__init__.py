@@ -1,0 +1,31 @@
+"""CPU oracle for the Aegis analyze hot path -- TEST INFRASTRUCTURE ONLY.
+
+This package is a NumPy/SciPy restatement of the arithmetic that the reference
+(`/root/reference/aegis_engine.py:41-75`) delegates to librosa, plus the
+reference's own frame->event logic.  It exists so that the HIP path can be
+checked; it is never the thing that is shipped or measured.  Only `tests/`,
+`__graft_entry__.smoke()` and the `cpu_baseline` leg of `bench.py` may import
+it.  The product package (`spectrogram-midi_amd/`) must not.
+
+PARITY PIN STATUS
+-----------------
+* `oracle.rake`  (reference `aegis_engine_core/vision.py:3-38`): PINNED.  The
+  reference module is NumPy-only and importable in the build container; golden
+  masks generated from it are committed under `tests/golden/rake_*.npz`
+  (generator: `tests/golden/make_rake_golden.py`).
+* everything that the reference delegates to **librosa** (un-vendored,
+  un-pinned: `/root/reference/requirements.txt:1`; not installed here, no
+  network): **PARITY UNPINNED**.  The reference holds no golden vectors or
+  asserting tests for this path.  The restatement
+  follows librosa 0.10.x as published (`core/spectrum.py`, `filters.py`,
+  `feature/spectral.py`, `core/pitch.py`, `sequence.py`, `core/convert.py`)
+  under NumPy-1.x dtype rules (np.fft upcasts float32 input to float64), is
+  stamped "librosa-0.10-semantics" in every fixture, and is anchored by analytic
+  known answers (tests/test_oracle_known_answers.py).
+* `oracle.events` / `oracle.smf` (reference `aegis_engine_core/midi_logic.py`,
+  `aegis_engine.py:98-179`; mido un-vendored): unpinned for the same reason;
+  the SMF byte layout follows the Standard MIDI File 1.0 spec as mido 1.3
+  writes it (running status off, explicit end_of_track).
+"""
+
+SEMANTICS = "librosa-0.10-semantics/numpy1-dtypes"
