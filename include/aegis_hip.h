@@ -1,0 +1,129 @@
+/* aegis_hip.h -- C ABI of libaegis_hip.so, the MI355X (gfx950) implementation of
+ * the Aegis Engine analyze hot path.
+ *
+ * The reference has no FFI of its own: its seam is the Python class
+ * `AegisEngine` (/root/reference/aegis_engine.py:16-216), which hands the
+ * per-frame arithmetic to librosa.  Each entry point below names the reference
+ * call(s) it replaces; INTEGRATION.md shows the ctypes stub a maintainer would
+ * add to aegis_engine.py.  Plain pointers and sizes only; nothing is thrown
+ * across the boundary; every function returns 0 or a negative errno-style code
+ * and leaves a message retrievable with aegis_last_error().
+ *
+ * Frame convention (librosa center=True, pad_mode="constant"):
+ *   n_frames(clip) = 1 + n_samples / hop_length           -> aegis_frames_for()
+ * Batch outputs are concatenated clip after clip in that frame order.
+ */
+#ifndef AEGIS_HIP_H
+#define AEGIS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AEGIS_ABI_VERSION 1
+
+/* return codes */
+#define AEGIS_OK 0
+#define AEGIS_ERR_INVALID (-22)     /* bad argument / unsupported configuration */
+#define AEGIS_ERR_NOMEM (-12)       /* host or device allocation failed */
+#define AEGIS_ERR_DEVICE (-5)       /* HIP runtime error (no device, launch failure) */
+#define AEGIS_ERR_UNSUPPORTED (-95) /* valid request this build cannot serve */
+
+/* stage selection bits for aegis_analyze_*(): which outputs are produced */
+#define AEGIS_STAGE_MEL 0x1   /* mel power -> dB image      aegis_engine.py:25-26 */
+#define AEGIS_STAGE_RAKE 0x2  /* rake mask (implies MEL)    aegis_engine.py:54, vision.py:3-38 */
+#define AEGIS_STAGE_PYIN 0x4  /* f0 / voiced / voiced_prob  aegis_engine.py:63,67, worker.py:9-15 */
+#define AEGIS_STAGE_RMS 0x8   /* frame RMS                  aegis_engine.py:70 */
+#define AEGIS_STAGE_ALL 0xF
+
+typedef struct aegis_handle aegis_handle;
+
+/* Replaces AegisEngine.__init__ (aegis_engine.py:17-20) plus the librosa
+ * defaults the reference relies on.  Zero / NaN fields take the default. */
+typedef struct aegis_config {
+    int32_t sample_rate;        /* 44100 (v2 engine: 22050, aegis_engine_financial.py:36) */
+    int32_t hop_length;         /* 512 */
+    int32_t n_fft;              /* 2048 (mel STFT; pYIN/RMS frame_length is librosa's fixed 2048) */
+    int32_t n_mels;             /* 128 */
+    double fmin;                /* pYIN fmin; 0 -> note_to_hz('E2') = 82.4068892282175 */
+    double fmax;                /* pYIN fmax; 0 -> note_to_hz('C6') = 1046.5022612023945 */
+    int32_t device;             /* HIP device ordinal; -1 = host tables only (no GPU touched:
+                                   aegis_get_table/param work, analyze calls fail with AEGIS_ERR_DEVICE) */
+    int32_t reserved;
+    int64_t max_frames_per_pass; /* workspace bound; 0 -> default (1<<21 frames, ~15 KB each) */
+} aegis_config;
+
+/* Per-batch outputs, concatenated over clips.  Any pointer may be NULL to skip
+ * that output.  Used with host pointers by aegis_analyze_batch() and with device
+ * pointers by aegis_analyze_batch_device().  dtypes follow the reference's
+ * raw_data dict (aegis_engine.py:72-75). */
+typedef struct aegis_outputs {
+    double *f0;           /* [F_total]  Hz, NaN where unvoiced (librosa.pyin fill_na) */
+    uint8_t *voiced_flag; /* [F_total]  0/1 */
+    double *voiced_prob;  /* [F_total] */
+    float *rms;           /* [F_total] */
+    uint8_t *rake_mask;   /* [F_total]  0/1 */
+    float *S_dB;          /* per clip [n_mels, F_clip] C-order, clip after clip (n_mels*F_total) */
+} aegis_outputs;
+
+int aegis_abi_version(void);
+
+/* aegis_engine.py:17-20.  Builds the device tables (Hann window, Slaney mel
+ * filterbank, pYIN priors, HMM log-transitions) and the workspace. */
+int aegis_create(const aegis_config *cfg, aegis_handle **out);
+void aegis_destroy(aegis_handle *h);
+const char *aegis_last_error(const aegis_handle *h); /* h may be NULL: last create error */
+
+/* F = 1 + n_samples / hop_length  (librosa framing used by every stage). */
+int64_t aegis_frames_for(const aegis_handle *h, int64_t n_samples);
+
+/* aegis_engine.py:50-75 for a batch of decoded clips (float32 mono PCM in host
+ * memory): mel -> dB -> rake mask, pYIN, RMS.  Blocking; does H2D, kernels, D2H.
+ * `stages` is a bitmask of AEGIS_STAGE_*.  Clips of length 0 produce 1 frame of
+ * silence (the Python layer returns None before calling, aegis_engine.py:51). */
+int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t *n_samples,
+                        int32_t n_clips, double rake_sensitivity, uint32_t stages,
+                        aegis_outputs *host_out);
+
+/* Same computation with the PCM already resident in device memory:
+ * clip c occupies d_pcm[sample_offsets[c] .. sample_offsets[c+1]); `sample_offsets`
+ * is a host array of n_clips+1 entries.  Outputs are device pointers.  Work is
+ * enqueued on `stream` (a hipStream_t, NULL = the handle's own stream) and the
+ * call returns without synchronising unless `sync` is non-zero. */
+int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
+                               int32_t n_clips, double rake_sensitivity, uint32_t stages,
+                               aegis_outputs *device_out, void *stream, int32_t sync);
+
+/* --- introspection used by the tests (no reference counterpart) ------------- */
+
+/* Host-side copies of the tables the kernels use.  `name` is one of
+ * "hann" f64[n_fft], "mel_dense" f32[n_mels*(1+n_fft/2)], "thresholds" f64[101],
+ * "beta_probs" f64[100], "beta_cumsum" f64[101], "boltz_fact" f64[n], "boltz_exp" f64[n],
+ * "log_trans_band" f64[4*n_cls*width], "freqs" f64[n_pitch_bins], "twiddle" f64[2*n_fft].
+ * Returns the element count (or a negative code); copies min(count, cap) elements. */
+int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int64_t cap);
+
+/* Scalar parameters derived at create time.  name in {"min_period","max_period",
+ * "n_lags","n_pitch_bins","transition_width","n_trans_classes","max_frames_per_pass",
+ * "lag_stride","yin_stride","obs_stride","last_frames"}. */
+int64_t aegis_get_param(const aegis_handle *h, const char *name);
+
+/* Copies an intermediate of the most recent pass (device -> host), for stage-level
+ * parity tests.  name in {"acf" f64[F*lag_stride], "yin" f64[F*yin_stride],
+ * "logobs" f64[F*obs_stride], "logunv" f64[F], "states" i32[F], "melpow" f32[F*n_mels]}.
+ * Returns the element count available; copies min(count, cap). */
+int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t cap);
+
+/* Kernel timing of the most recent aegis_analyze_batch_device() with sync != 0,
+ * measured with hipEvents on the stream the kernels ran on.  name in
+ * {"frame_fft","yin_seq","pyin_obs","viterbi","finalize","total"}; milliseconds,
+ * negative when unavailable.  aegis_set_profiling(h, 1) enables the events. */
+int aegis_set_profiling(aegis_handle *h, int32_t on);
+double aegis_last_kernel_ms(const aegis_handle *h, const char *name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AEGIS_HIP_H */

@@ -157,7 +157,9 @@ def transition_local_triangle(n_states, width):
 
 def transition_matrix(p):
     loc = transition_local_triangle(p.n_pitch_bins, p.transition_width)
-    sw = np.array([[1 - p.switch_prob, p.switch_prob], [p.switch_prob, 1 - p.switch_prob]])
+    # sequence.transition_loop(2, 1 - switch_prob): off-diagonal = (1.0 - prob) / (n_states - 1)
+    stay = 1 - p.switch_prob
+    sw = np.array([[stay, (1.0 - stay) / 1], [(1.0 - stay) / 1, stay]])
     return np.kron(sw, loc)
 
 

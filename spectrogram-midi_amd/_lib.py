@@ -1,0 +1,194 @@
+"""ctypes binding of libaegis_hip.so (include/aegis_hip.h).  Fails loudly when the
+extension has not been built: `python -c "import __graft_entry__ as g; g.build()"`."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaegis_hip.so")
+
+STAGE_MEL, STAGE_RAKE, STAGE_PYIN, STAGE_RMS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
+OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95
+
+
+class AegisError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libaegis_hip error {code}: {msg}")
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("sample_rate", C.c_int32), ("hop_length", C.c_int32), ("n_fft", C.c_int32),
+                ("n_mels", C.c_int32), ("fmin", C.c_double), ("fmax", C.c_double),
+                ("device", C.c_int32), ("reserved", C.c_int32), ("max_frames_per_pass", C.c_int64)]
+
+
+class Outputs(C.Structure):
+    _fields_ = [("f0", C.c_void_p), ("voiced_flag", C.c_void_p), ("voiced_prob", C.c_void_p),
+                ("rms", C.c_void_p), ("rake_mask", C.c_void_p), ("S_dB", C.c_void_p)]
+
+
+EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
+           "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms")
+
+_lib = None
+
+
+def load():
+    """Returns the loaded library; raises ImportError with build instructions if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension must be built (make -C {_HERE}/csrc, or "
+            "__graft_entry__.build()).  There is no CPU fallback for the analyze path.")
+    lib = C.CDLL(LIB_PATH)
+    lib.aegis_abi_version.restype = C.c_int
+    lib.aegis_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.aegis_create.restype = C.c_int
+    lib.aegis_destroy.argtypes = [C.c_void_p]
+    lib.aegis_destroy.restype = None
+    lib.aegis_last_error.argtypes = [C.c_void_p]
+    lib.aegis_last_error.restype = C.c_char_p
+    lib.aegis_frames_for.argtypes = [C.c_void_p, C.c_int64]
+    lib.aegis_frames_for.restype = C.c_int64
+    lib.aegis_analyze_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32,
+                                        C.c_double, C.c_uint32, C.POINTER(Outputs)]
+    lib.aegis_analyze_batch.restype = C.c_int
+    lib.aegis_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32,
+                                               C.c_double, C.c_uint32, C.POINTER(Outputs), C.c_void_p, C.c_int32]
+    lib.aegis_analyze_batch_device.restype = C.c_int
+    lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.aegis_get_table.restype = C.c_int64
+    lib.aegis_get_param.argtypes = [C.c_void_p, C.c_char_p]
+    lib.aegis_get_param.restype = C.c_int64
+    lib.aegis_debug_fetch.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.aegis_debug_fetch.restype = C.c_int64
+    lib.aegis_set_profiling.argtypes = [C.c_void_p, C.c_int32]
+    lib.aegis_set_profiling.restype = C.c_int
+    lib.aegis_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
+    lib.aegis_last_kernel_ms.restype = C.c_double
+    _lib = lib
+    return lib
+
+
+_TABLE_DTYPES = {"mel_dense": np.float32}
+_DEBUG_DTYPES = {"states": np.int32, "melpow": np.float32}
+
+
+class Handle:
+    """One analyze context (tables + workspace + stream) on one GPU.  device=-1 builds the
+    host tables only (no GPU touched)."""
+
+    def __init__(self, sample_rate=44100, hop_length=512, n_fft=2048, n_mels=128, fmin=0.0, fmax=0.0,
+                 device=0, max_frames_per_pass=0):
+        self.lib = load()
+        cfg = Config(sample_rate, hop_length, n_fft, n_mels, fmin, fmax, device, 0, max_frames_per_pass)
+        h = C.c_void_p()
+        rc = self.lib.aegis_create(C.byref(cfg), C.byref(h))
+        if rc != OK:
+            raise AegisError(rc, self.lib.aegis_last_error(None).decode())
+        self._h = h
+        self.sr, self.hop, self.n_fft, self.n_mels, self.device = sample_rate, hop_length, n_fft, n_mels, device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.aegis_destroy(self._h)
+            self._h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != OK:
+            raise AegisError(rc, self.lib.aegis_last_error(self._h).decode())
+
+    def frames_for(self, n_samples):
+        return int(self.lib.aegis_frames_for(self._h, int(n_samples)))
+
+    def param(self, name):
+        v = int(self.lib.aegis_get_param(self._h, name.encode()))
+        if v < 0:
+            raise AegisError(v, f"unknown parameter {name}")
+        return v
+
+    def table(self, name):
+        n = int(self.lib.aegis_get_table(self._h, name.encode(), None, 0))
+        if n < 0:
+            raise AegisError(n, f"unknown table {name}")
+        out = np.empty(n, dtype=_TABLE_DTYPES.get(name, np.float64))
+        self.lib.aegis_get_table(self._h, name.encode(), out.ctypes.data, n)
+        return out
+
+    def debug_fetch(self, name):
+        n = int(self.lib.aegis_debug_fetch(self._h, name.encode(), None, 0))
+        if n < 0:
+            raise AegisError(n, self.lib.aegis_last_error(self._h).decode())
+        out = np.empty(n, dtype=_DEBUG_DTYPES.get(name, np.float64))
+        got = int(self.lib.aegis_debug_fetch(self._h, name.encode(), out.ctypes.data, n))
+        if got < 0:
+            raise AegisError(got, self.lib.aegis_last_error(self._h).decode())
+        return out
+
+    def set_profiling(self, on=True):
+        self._check(self.lib.aegis_set_profiling(self._h, 1 if on else 0))
+
+    def kernel_ms(self, name):
+        return float(self.lib.aegis_last_kernel_ms(self._h, name.encode()))
+
+    def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True):
+        """clips: list of float32 1-D arrays (host).  Returns a list of per-clip dicts with the
+        dtypes of the reference's raw_data (aegis_engine.py:72-75); f0 keeps NaN where unvoiced."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        n = len(clips)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in clips])
+        lens = (C.c_int64 * n)(*[len(c) for c in clips])
+        frames = [self.frames_for(len(c)) for c in clips]
+        F = sum(frames)
+        if stages & STAGE_RAKE:
+            stages |= STAGE_MEL
+        bufs = {}
+        out = Outputs()
+        if stages & STAGE_PYIN:
+            bufs["f0"] = np.empty(F, np.float64)
+            bufs["voiced_flag"] = np.empty(F, np.uint8)
+            bufs["voiced_prob"] = np.empty(F, np.float64)
+        if stages & STAGE_RMS:
+            bufs["rms"] = np.empty(F, np.float32)
+        if stages & STAGE_RAKE:
+            bufs["rake_mask"] = np.empty(F, np.uint8)
+        if (stages & STAGE_MEL) and want_sdb:
+            bufs["S_dB"] = np.empty(F * self.n_mels, np.float32)
+        for k, v in bufs.items():
+            setattr(out, k, v.ctypes.data)
+        self._check(self.lib.aegis_analyze_batch(self._h, ptrs, lens, n, float(rake_sensitivity),
+                                                 int(stages), C.byref(out)))
+        res, fo = [], 0
+        for c, Fc in zip(clips, frames):
+            d = {}
+            for k, v in bufs.items():
+                if k == "S_dB":
+                    d[k] = v[fo * self.n_mels:(fo + Fc) * self.n_mels].reshape(self.n_mels, Fc).copy()
+                elif k in ("voiced_flag", "rake_mask"):
+                    d[k] = v[fo:fo + Fc].astype(bool)
+                else:
+                    d[k] = v[fo:fo + Fc].copy()
+            res.append(d)
+            fo += Fc
+        return res
+
+    def analyze_batch_device(self, d_pcm_ptr, sample_offsets, outputs, rake_sensitivity=0.6,
+                             stages=STAGE_ALL, stream=None, sync=True):
+        """PCM and outputs already in device memory (raw pointers as ints).  `outputs` maps the
+        aegis_outputs field names to device pointers."""
+        off = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        out = Outputs()
+        for k, v in outputs.items():
+            setattr(out, k, int(v) if v else None)
+        self._check(self.lib.aegis_analyze_batch_device(
+            self._h, C.c_void_p(int(d_pcm_ptr)), off.ctypes.data_as(C.POINTER(C.c_int64)), len(off) - 1,
+            float(rake_sensitivity), int(stages), C.byref(out), C.c_void_p(stream or 0), 1 if sync else 0))

@@ -1,0 +1,474 @@
+// C ABI of libaegis_hip.so (see include/aegis_hip.h).  Host-side orchestration:
+// table upload, workspace management, ragged-batch pass planning, kernel launches
+// on one HIP stream per handle, optional hipEvent timing per kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/aegis_hip.h"
+#include "kernels.h"
+#include "tables.h"
+
+using namespace aegis;
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct PassMeta {   // host copies kept alive until the stream has consumed them
+    std::vector<int64_t> sample_off, frame_off, chunk_off;
+    std::vector<int32_t> order;
+};
+
+}  // namespace
+
+struct aegis_handle {
+    Tables tab;
+    DevTables dt{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int64_t max_frames_per_pass = 0;
+    mutable std::string err;
+    std::vector<void *> table_allocs;
+    // workspace (grow-only)
+    DevBuf acf, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
+    DevBuf sample_off, frame_off, order;
+    DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb;
+    int32_t lag_stride = 0, yin_stride = 0, obs_stride = 0;
+    std::vector<PassMeta> metas;
+    // last pass geometry for aegis_debug_fetch
+    int64_t last_frames = 0;
+    // profiling
+    bool profiling = false;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
+    std::map<std::string, double> last_ms;
+};
+
+namespace {
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess) {                                                                \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);                      \
+            return AEGIS_ERR_DEVICE;                                                            \
+        }                                                                                       \
+    } while (0)
+
+int ensure(aegis_handle *h, DevBuf &b, size_t bytes) {
+    if (bytes <= b.cap) return AEGIS_OK;
+    if (b.p) {
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        h->err = "hipMalloc(" + std::to_string(want) + " bytes): " + hipGetErrorString(e);
+        return AEGIS_ERR_NOMEM;
+    }
+    b.cap = want;
+    return AEGIS_OK;
+}
+
+template <typename T>
+int upload_table(aegis_handle *h, const std::vector<T> &v, const T **dst) {
+    void *d = nullptr;
+    const size_t bytes = std::max<size_t>(v.size() * sizeof(T), 16);
+    HIPCHK(h, hipMalloc(&d, bytes));
+    h->table_allocs.push_back(d);
+    if (!v.empty()) HIPCHK(h, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    *dst = static_cast<const T *>(d);
+    return AEGIS_OK;
+}
+
+void free_buf(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr; b.cap = 0;
+}
+
+void begin_event(aegis_handle *h, const char *name, hipStream_t s) {
+    if (!h->profiling) return;
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+    (void)hipEventRecord(a, s);
+    h->events.push_back({name, {a, b}});
+}
+void end_event(aegis_handle *h, hipStream_t s) {
+    if (!h->profiling || h->events.empty()) return;
+    (void)hipEventRecord(h->events.back().second.second, s);
+}
+void collect_events(aegis_handle *h) {
+    h->last_ms.clear();
+    double total = 0;
+    for (auto &ev : h->events) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, ev.second.first, ev.second.second) == hipSuccess) {
+            h->last_ms[ev.first] += ms;
+            total += ms;
+        }
+        (void)hipEventDestroy(ev.second.first);
+        (void)hipEventDestroy(ev.second.second);
+    }
+    h->events.clear();
+    h->last_ms["total"] = total;
+}
+
+}  // namespace
+
+extern "C" {
+
+int aegis_abi_version(void) { return AEGIS_ABI_VERSION; }
+
+const char *aegis_last_error(const aegis_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int aegis_create(const aegis_config *cfg, aegis_handle **out) {
+    if (!out) { g_create_error = "out == NULL"; return AEGIS_ERR_INVALID; }
+    *out = nullptr;
+    aegis_config c{};
+    if (cfg) c = *cfg;
+    if (c.sample_rate == 0) c.sample_rate = 44100;
+    if (c.hop_length == 0) c.hop_length = 512;
+    if (c.n_fft == 0) c.n_fft = 2048;
+    if (c.n_mels == 0) c.n_mels = 128;
+    if (!(c.fmin > 0)) c.fmin = 82.4068892282175;      // note_to_hz('E2'), aegis_engine.py:63
+    if (!(c.fmax > 0)) c.fmax = 1046.5022612023945;    // note_to_hz('C6')
+    if (c.max_frames_per_pass <= 0) c.max_frames_per_pass = (int64_t)1 << 21;
+
+    auto *h = new (std::nothrow) aegis_handle();
+    if (!h) { g_create_error = "out of host memory"; return AEGIS_ERR_NOMEM; }
+    const std::string terr = h->tab.build(c.sample_rate, c.hop_length, c.n_fft, c.n_mels, c.fmin, c.fmax);
+    if (!terr.empty()) { g_create_error = terr; delete h; return AEGIS_ERR_INVALID; }
+    h->device = c.device;
+    h->max_frames_per_pass = c.max_frames_per_pass;
+
+    h->lag_stride = (h->tab.max_period + 1 + 7) & ~7;
+    h->yin_stride = (h->tab.n_lags + 7) & ~7;
+    h->obs_stride = (h->tab.n_bins + 7) & ~7;
+    if (c.device == -1) { *out = h; return AEGIS_OK; }   // host tables only
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e);
+        delete h; return AEGIS_ERR_DEVICE;
+    }
+    if (c.device < 0 || c.device >= ndev) { g_create_error = "device ordinal out of range"; delete h; return AEGIS_ERR_INVALID; }
+    auto fail = [&](int code) { g_create_error = h->err; aegis_destroy(h); return code; };
+#define CRT(expr) do { int rc__ = (expr); if (rc__ != AEGIS_OK) return fail(rc__); } while (0)
+#define CRTHIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e__); return fail(AEGIS_ERR_DEVICE); } } while (0)
+    CRTHIP(hipSetDevice(c.device));
+    CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CRTHIP(viterbi_configure());
+
+    const Tables &t = h->tab;
+    CRT(upload_table(h, t.hann, &h->dt.hann));
+    CRT(upload_table(h, t.mel_start, &h->dt.mel_start));
+    CRT(upload_table(h, t.mel_len, &h->dt.mel_len));
+    CRT(upload_table(h, t.mel_off, &h->dt.mel_off));
+    CRT(upload_table(h, t.mel_w, &h->dt.mel_w));
+    CRT(upload_table(h, t.thresholds, &h->dt.thresholds));
+    CRT(upload_table(h, t.beta_probs, &h->dt.beta_probs));
+    CRT(upload_table(h, t.beta_cumsum, &h->dt.beta_cumsum));
+    CRT(upload_table(h, t.boltz_fact, &h->dt.boltz_fact));
+    CRT(upload_table(h, t.boltz_exp, &h->dt.boltz_exp));
+    CRT(upload_table(h, t.log_trans_band, &h->dt.lt_band));
+    CRT(upload_table(h, t.freqs, &h->dt.freqs));
+    {
+        const double *tw = nullptr;
+        CRT(upload_table(h, t.twiddle, &tw));
+        h->dt.twiddle = reinterpret_cast<const double2 *>(tw);
+    }
+#undef CRT
+#undef CRTHIP
+    *out = h;
+    return AEGIS_OK;
+}
+
+void aegis_destroy(aegis_handle *h) {
+    if (!h) return;
+    if (h->device < 0) { delete h; return; }
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (void *p : h->table_allocs) (void)hipFree(p);
+    for (DevBuf *b : {&h->acf, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
+                      &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
+                      &h->order, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
+                      &h->io_sdb})
+        free_buf(*b);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int64_t aegis_frames_for(const aegis_handle *h, int64_t n_samples) {
+    if (!h || n_samples < 0) return AEGIS_ERR_INVALID;
+    return 1 + n_samples / h->tab.hop;
+}
+
+int aegis_set_profiling(aegis_handle *h, int32_t on) {
+    if (!h) return AEGIS_ERR_INVALID;
+    h->profiling = on != 0;
+    return AEGIS_OK;
+}
+
+double aegis_last_kernel_ms(const aegis_handle *h, const char *name) {
+    if (!h || !name) return -1.0;
+    auto it = h->last_ms.find(name);
+    return it == h->last_ms.end() ? -1.0 : it->second;
+}
+
+int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
+                               int32_t n_clips, double rake_sensitivity, uint32_t stages,
+                               aegis_outputs *dout, void *stream_v, int32_t sync) {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_clips < 0 || (n_clips > 0 && (!sample_offsets || !dout))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    if (n_clips == 0) return AEGIS_OK;
+    if (stages & AEGIS_STAGE_RAKE) stages |= AEGIS_STAGE_MEL;
+    stages &= AEGIS_STAGE_ALL;
+    const Tables &t = h->tab;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = stream_v ? static_cast<hipStream_t>(stream_v) : h->stream;
+
+    // per-clip frame counts and validation
+    std::vector<int64_t> frames(n_clips);
+    for (int i = 0; i < n_clips; ++i) {
+        const int64_t n = sample_offsets[i + 1] - sample_offsets[i];
+        if (n < 0) { h->err = "sample_offsets must be non-decreasing"; return AEGIS_ERR_INVALID; }
+        if (n > 0 && !d_pcm) { h->err = "d_pcm == NULL"; return AEGIS_ERR_INVALID; }
+        frames[i] = 1 + n / t.hop;
+        if (frames[i] > h->max_frames_per_pass) {
+            h->err = "clip of " + std::to_string(frames[i]) + " frames exceeds max_frames_per_pass=" +
+                     std::to_string(h->max_frames_per_pass);
+            return AEGIS_ERR_INVALID;
+        }
+    }
+    // host metadata from earlier calls is no longer referenced once the stream drained
+    if (!h->metas.empty()) { HIPCHK(h, hipStreamSynchronize(s)); h->metas.clear(); }
+    if (h->profiling) { for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); } h->events.clear(); }
+
+    // vision.py:23-25
+    const double ms_per_frame = ((double)t.hop / (double)t.sr) * 1000;
+    const int rake_min = (int)(10 / ms_per_frame), rake_max = (int)(30 / ms_per_frame);
+
+    int first = 0;
+    int64_t frame_base = 0;   // frames before this pass (for output offsets)
+    while (first < n_clips) {
+        int last = first;
+        int64_t fp = 0;
+        while (last < n_clips && fp + frames[last] <= h->max_frames_per_pass) { fp += frames[last]; ++last; }
+        const int nc = last - first;
+        h->metas.emplace_back();
+        PassMeta &m = h->metas.back();
+        m.sample_off.assign(sample_offsets + first, sample_offsets + last + 1);
+        m.frame_off.resize(nc + 1);
+        m.chunk_off.resize(nc + 1);
+        m.frame_off[0] = 0; m.chunk_off[0] = 0;
+        for (int i = 0; i < nc; ++i) {
+            m.frame_off[i + 1] = m.frame_off[i] + frames[first + i];
+            m.chunk_off[i + 1] = m.chunk_off[i] + (frames[first + i] - 1 + kViterbiChunk - 1) / kViterbiChunk;
+        }
+        m.order.resize(nc);
+        std::iota(m.order.begin(), m.order.end(), 0);
+        std::stable_sort(m.order.begin(), m.order.end(),
+                         [&](int a, int b) { return frames[first + a] > frames[first + b]; });
+        const int64_t nchunks = m.chunk_off[nc];
+        const int S = 2 * t.n_bins;
+
+        int rc;
+#define ENS(buf, bytes) if ((rc = ensure(h, h->buf, (size_t)(bytes))) != AEGIS_OK) return rc
+        ENS(sample_off, (nc + 1) * 8); ENS(frame_off, (nc + 1) * 8); ENS(order, nc * 4); ENS(chunk_off, (nc + 1) * 8);
+        if (stages & AEGIS_STAGE_PYIN) {
+            ENS(acf, fp * h->lag_stride * 8); ENS(yin, fp * h->yin_stride * 8);
+            ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8);
+            ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
+            ENS(states, fp * 4);
+        }
+        if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
+#undef ENS
+        HIPCHK(h, hipMemcpyAsync(h->sample_off.p, m.sample_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->frame_off.p, m.frame_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->chunk_off.p, m.chunk_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(h->order.p, m.order.data(), nc * 4, hipMemcpyHostToDevice, s));
+        if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(h->clipmax.p, 0, nc * 4, s));
+
+        PassParams p{};
+        p.sr = t.sr; p.hop = t.hop; p.n_mels = t.n_mels;
+        p.min_period = t.min_period; p.max_period = t.max_period; p.n_lags = t.n_lags;
+        p.n_bins = t.n_bins; p.half_width = t.half_width; p.width = t.width; p.n_cls = t.n_cls;
+        p.fmin = t.fmin; p.log_tiny = t.log_tiny; p.log_pinit = t.log_pinit;
+        p.stages = stages;
+        p.pcm = d_pcm;
+        p.sample_off = static_cast<const int64_t *>(h->sample_off.p);
+        p.frame_off = static_cast<const int64_t *>(h->frame_off.p);
+        p.order = static_cast<const int32_t *>(h->order.p);
+        p.n_clips = nc; p.n_frames = fp;
+        p.acf = static_cast<double *>(h->acf.p); p.lag_stride = h->lag_stride;
+        p.yin = static_cast<double *>(h->yin.p); p.yin_stride = h->yin_stride;
+        p.logobs = static_cast<double *>(h->logobs.p); p.obs_stride = h->obs_stride;
+        p.logunv = static_cast<double *>(h->logunv.p);
+        p.ptr = static_cast<uint16_t *>(h->ptr.p);
+        p.cmap = static_cast<uint16_t *>(h->cmap.p);
+        p.chunk_off = static_cast<int64_t *>(h->chunk_off.p);
+        p.bnd = static_cast<int32_t *>(h->bnd.p);
+        p.states = static_cast<int32_t *>(h->states.p);
+        p.melpow = static_cast<float *>(h->melpow.p);
+        p.clipmax = static_cast<uint32_t *>(h->clipmax.p);
+        p.rake_raw = static_cast<uint8_t *>(h->rake_raw.p);
+        const bool py = stages & AEGIS_STAGE_PYIN;
+        p.out_f0 = (py && dout->f0) ? dout->f0 + frame_base : nullptr;
+        p.out_voiced = (py && dout->voiced_flag) ? dout->voiced_flag + frame_base : nullptr;
+        p.out_vprob = (py && dout->voiced_prob) ? dout->voiced_prob + frame_base : nullptr;
+        p.out_rms = ((stages & AEGIS_STAGE_RMS) && dout->rms) ? dout->rms + frame_base : nullptr;
+        p.out_rake = ((stages & AEGIS_STAGE_RAKE) && dout->rake_mask) ? dout->rake_mask + frame_base : nullptr;
+        p.out_sdb = ((stages & AEGIS_STAGE_MEL) && dout->S_dB) ? dout->S_dB + (int64_t)t.n_mels * frame_base : nullptr;
+        p.rake_ratio = rake_sensitivity;
+        p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
+
+        begin_event(h, "frame_fft", s); launch_frame_fft(p, h->dt, s); end_event(h, s);
+        if (py) {
+            begin_event(h, "yin_seq", s); launch_yin_seq(p, h->dt, s); end_event(h, s);
+            begin_event(h, "pyin_obs", s); launch_pyin_obs(p, h->dt, s); end_event(h, s);
+            begin_event(h, "viterbi", s);
+            hipError_t ve = launch_viterbi(p, h->dt, s);
+            end_event(h, s);
+            if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+        }
+        begin_event(h, "finalize", s); launch_finalize(p, h->dt, s); end_event(h, s);
+        HIPCHK(h, hipGetLastError());
+        h->last_frames = fp;
+        frame_base += fp;
+        first = last;
+    }
+    if (sync) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        h->metas.clear();
+        if (h->profiling) collect_events(h);
+    }
+    return AEGIS_OK;
+}
+
+int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
+                        double rake_sensitivity, uint32_t stages, aegis_outputs *out) {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    if (n_clips == 0) return AEGIS_OK;
+    if (stages & AEGIS_STAGE_RAKE) stages |= AEGIS_STAGE_MEL;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    std::vector<int64_t> off(n_clips + 1, 0);
+    int64_t F = 0;
+    for (int i = 0; i < n_clips; ++i) {
+        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) { h->err = "bad clip " + std::to_string(i); return AEGIS_ERR_INVALID; }
+        // keep every clip 16-byte aligned in the packed device buffer
+        off[i + 1] = off[i] + n_samples[i];
+        F += 1 + n_samples[i] / h->tab.hop;
+    }
+    int rc;
+    if ((rc = ensure(h, h->io_pcm, (size_t)std::max<int64_t>(off[n_clips], 1) * 4)) != AEGIS_OK) return rc;
+    hipStream_t s = h->stream;
+    for (int i = 0; i < n_clips; ++i)
+        if (n_samples[i] > 0)
+            HIPCHK(h, hipMemcpyAsync(static_cast<float *>(h->io_pcm.p) + off[i], pcm[i], n_samples[i] * 4,
+                                     hipMemcpyHostToDevice, s));
+    aegis_outputs d{};
+    const int nm = h->tab.n_mels;
+    if ((stages & AEGIS_STAGE_PYIN) && out->f0) { if ((rc = ensure(h, h->io_f0, F * 8))) return rc; d.f0 = static_cast<double *>(h->io_f0.p); }
+    if ((stages & AEGIS_STAGE_PYIN) && out->voiced_flag) { if ((rc = ensure(h, h->io_voiced, F))) return rc; d.voiced_flag = static_cast<uint8_t *>(h->io_voiced.p); }
+    if ((stages & AEGIS_STAGE_PYIN) && out->voiced_prob) { if ((rc = ensure(h, h->io_vprob, F * 8))) return rc; d.voiced_prob = static_cast<double *>(h->io_vprob.p); }
+    if ((stages & AEGIS_STAGE_RMS) && out->rms) { if ((rc = ensure(h, h->io_rms, F * 4))) return rc; d.rms = static_cast<float *>(h->io_rms.p); }
+    if ((stages & AEGIS_STAGE_RAKE) && out->rake_mask) { if ((rc = ensure(h, h->io_rake, F))) return rc; d.rake_mask = static_cast<uint8_t *>(h->io_rake.p); }
+    if ((stages & AEGIS_STAGE_MEL) && out->S_dB) { if ((rc = ensure(h, h->io_sdb, F * nm * 4))) return rc; d.S_dB = static_cast<float *>(h->io_sdb.p); }
+    rc = aegis_analyze_batch_device(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
+                                    rake_sensitivity, stages, &d, s, 0);
+    if (rc != AEGIS_OK) return rc;
+    if (d.f0) HIPCHK(h, hipMemcpyAsync(out->f0, d.f0, F * 8, hipMemcpyDeviceToHost, s));
+    if (d.voiced_flag) HIPCHK(h, hipMemcpyAsync(out->voiced_flag, d.voiced_flag, F, hipMemcpyDeviceToHost, s));
+    if (d.voiced_prob) HIPCHK(h, hipMemcpyAsync(out->voiced_prob, d.voiced_prob, F * 8, hipMemcpyDeviceToHost, s));
+    if (d.rms) HIPCHK(h, hipMemcpyAsync(out->rms, d.rms, F * 4, hipMemcpyDeviceToHost, s));
+    if (d.rake_mask) HIPCHK(h, hipMemcpyAsync(out->rake_mask, d.rake_mask, F, hipMemcpyDeviceToHost, s));
+    if (d.S_dB) HIPCHK(h, hipMemcpyAsync(out->S_dB, d.S_dB, (size_t)F * nm * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->metas.clear();
+    if (h->profiling) collect_events(h);
+    return AEGIS_OK;
+}
+
+int64_t aegis_get_param(const aegis_handle *h, const char *name) {
+    if (!h || !name) return AEGIS_ERR_INVALID;
+    const Tables &t = h->tab;
+    const std::string n(name);
+    if (n == "min_period") return t.min_period;
+    if (n == "max_period") return t.max_period;
+    if (n == "n_lags") return t.n_lags;
+    if (n == "n_pitch_bins") return t.n_bins;
+    if (n == "transition_width") return t.width;
+    if (n == "n_trans_classes") return t.n_cls;
+    if (n == "max_frames_per_pass") return h->max_frames_per_pass;
+    if (n == "lag_stride") return h->lag_stride;
+    if (n == "yin_stride") return h->yin_stride;
+    if (n == "obs_stride") return h->obs_stride;
+    if (n == "last_frames") return h->last_frames;
+    return AEGIS_ERR_INVALID;
+}
+
+int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int64_t cap) {
+    if (!h || !name) return AEGIS_ERR_INVALID;
+    const Tables &t = h->tab;
+    const std::string n(name);
+    const void *src = nullptr;
+    int64_t count = 0;
+    size_t esz = 8;
+    auto setd = [&](const std::vector<double> &v) { src = v.data(); count = (int64_t)v.size(); esz = 8; };
+    if (n == "hann") setd(t.hann);
+    else if (n == "thresholds") setd(t.thresholds);
+    else if (n == "beta_probs") setd(t.beta_probs);
+    else if (n == "beta_cumsum") setd(t.beta_cumsum);
+    else if (n == "boltz_fact") setd(t.boltz_fact);
+    else if (n == "boltz_exp") setd(t.boltz_exp);
+    else if (n == "log_trans_band") setd(t.log_trans_band);
+    else if (n == "freqs") setd(t.freqs);
+    else if (n == "twiddle") setd(t.twiddle);
+    else if (n == "mel_dense") { src = t.mel_dense.data(); count = (int64_t)t.mel_dense.size(); esz = 4; }
+    else return AEGIS_ERR_INVALID;
+    if (dst && cap > 0) std::memcpy(dst, src, (size_t)std::min(count, cap) * esz);
+    return count;
+}
+
+int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t cap) {
+    if (!h || !name) return AEGIS_ERR_INVALID;
+    const std::string n(name);
+    const int64_t F = h->last_frames;
+    const void *src = nullptr;
+    int64_t count = 0;
+    size_t esz = 8;
+    if (n == "acf") { src = h->acf.p; count = F * h->lag_stride; }
+    else if (n == "yin") { src = h->yin.p; count = F * h->yin_stride; }
+    else if (n == "logobs") { src = h->logobs.p; count = F * h->obs_stride; }
+    else if (n == "logunv") { src = h->logunv.p; count = F; }
+    else if (n == "states") { src = h->states.p; count = F; esz = 4; }
+    else if (n == "melpow") { src = h->melpow.p; count = F * h->tab.n_mels; esz = 4; }
+    else return AEGIS_ERR_INVALID;
+    if (h->device < 0 || !src) { h->err = "stage was not run"; return AEGIS_ERR_INVALID; }
+    if (dst && cap > 0) {
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(dst, src, (size_t)std::min(count, cap) * esz, hipMemcpyDeviceToHost));
+    }
+    return count;
+}
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Device-side parameter blocks and launch wrappers for the analyze kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace aegis {
+
+// Constant tables resident in HBM (built by tables.cpp, uploaded once per handle).
+struct DevTables {
+    const double *hann;        // [2048]
+    const int32_t *mel_start;  // [n_mels]
+    const int32_t *mel_len;    // [n_mels]
+    const int32_t *mel_off;    // [n_mels]
+    const float *mel_w;        // packed triangle weights
+    const double *thresholds;  // [101]
+    const double *beta_probs;  // [100]
+    const double *beta_cumsum; // [101]
+    const double *boltz_fact;  // [n]
+    const double *boltz_exp;   // [n]
+    const double *lt_band;     // [4][n_cls][width]
+    const double *freqs;       // [n_bins]
+    const double2 *twiddle;    // [2048]
+};
+
+// Geometry shared by all kernels of one pass.
+struct PassParams {
+    // configuration
+    int32_t sr, hop, n_mels;
+    int32_t min_period, max_period, n_lags;
+    int32_t n_bins, half_width, width, n_cls;
+    double fmin;
+    double log_tiny, log_pinit;
+    uint32_t stages;
+    // batch geometry (device arrays are per pass)
+    const float *pcm;            // all clips of the batch
+    const int64_t *sample_off;   // [n_clips+1] into pcm (this pass's clips)
+    const int64_t *frame_off;    // [n_clips+1] frame offsets relative to the pass
+    const int32_t *order;        // [n_clips] clip indices, longest first
+    int32_t n_clips;
+    int64_t n_frames;            // frames in this pass
+    // workspace (strides in elements)
+    double *acf;   int32_t lag_stride;   // [F][lag_stride]   lags 0..max_period
+    double *yin;   int32_t yin_stride;   // [F][yin_stride]   CMND for lags min..max
+    double *logobs; int32_t obs_stride;  // [F][obs_stride]   log(obs+tiny), voiced bins
+    double *logunv;                      // [F]               log(unvoiced obs+tiny)
+    uint16_t *ptr;                       // [F][2*n_bins]     Viterbi back-pointers
+    uint16_t *cmap;                      // [chunks][2*n_bins] composed chunk maps
+    int64_t *chunk_off;                  // [n_clips+1]       first chunk of each clip
+    int32_t *bnd;                        // [chunks]          state at each chunk end
+    int32_t *states;                     // [F]
+    float *melpow;                       // [F][n_mels]
+    uint32_t *clipmax;                   // [n_clips]  max mel power (float bits)
+    uint8_t *rake_raw;                   // [F]
+    // outputs for this pass (already offset to the pass's first frame; may be null)
+    double *out_f0; uint8_t *out_voiced; double *out_vprob; float *out_rms;
+    uint8_t *out_rake; float *out_sdb;   // out_sdb offset = n_mels * first frame of pass
+    double rake_ratio;
+    int32_t rake_min_frames, rake_max_frames;
+};
+
+constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
+
+void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s);
+void launch_yin_seq(const PassParams &p, const DevTables &t, hipStream_t s);
+void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
+hipError_t launch_viterbi(const PassParams &p, const DevTables &t, hipStream_t s);
+void launch_finalize(const PassParams &p, const DevTables &t, hipStream_t s);
+hipError_t viterbi_configure();   // raises the dynamic-LDS limit once
+
+}  // namespace aegis

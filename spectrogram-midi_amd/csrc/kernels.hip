@@ -1,0 +1,724 @@
+// HIP kernels for the Aegis analyze path on gfx950 (MI355X / CDNA4, wave64).
+//
+// Reference behaviour being reproduced (the arithmetic lives in librosa, which
+// /root/reference/aegis_engine.py:25-26,63,67,70 calls):
+//   frame_fft_kernel   melspectrogram power + feature.rms + the FFT autocorrelation
+//                      of pyin's difference function          
+//   yin_seq_kernel     running energy, difference, CMND        (P3, P4)
+//   pyin_obs_kernel    troughs, threshold prior, pitch-bin observation (P5-P10)
+//   viterbi_kernel     882-state log-Viterbi with chunked back-tracking (P11, P12)
+//   finalize kernels   power_to_db(ref=max), rake mask (vision.py:3-38), f0 decode
+//
+// Built with -ffp-contract=off: every multiply/add below rounds exactly where
+// NumPy rounds; fused operations are written as fma() where they are wanted.
+#include "kernels.h"
+
+#include <cfloat>
+#include <cmath>
+
+namespace aegis {
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_clip(const int64_t *__restrict__ frame_off, int n_clips, int64_t f) {
+    int lo = 0, hi = n_clips;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (frame_off[mid] <= f) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
+    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+
+// ------------------------------------------------------------------------------------------
+// 2048-point complex FFT, float64, Stockham autosort in LDS: five radix-4 passes and one
+// radix-2 pass, 256 threads.  Forward transform (e^{-2 pi i jk/N}); input and result in `a`,
+// `b` is the second buffer.  Caller synchronises before the call; returns synchronised.
+// ------------------------------------------------------------------------------------------
+template <int NS>
+__device__ __forceinline__ void fft_pass_r4(const double2 *__restrict__ in, double2 *__restrict__ out,
+                                            const double2 *__restrict__ tw, int tid) {
+#pragma unroll
+    for (int jj = 0; jj < 2; ++jj) {
+        const int j = tid + jj * 256;
+        const int k = j & (NS - 1);
+        double2 v0 = in[j], v1 = in[j + 512], v2 = in[j + 1024], v3 = in[j + 1536];
+        if (NS > 1) {
+            const int m = k * (2048 / (NS * 4));
+            v1 = cmul(v1, tw[m]);
+            v2 = cmul(v2, tw[2 * m]);
+            v3 = cmul(v3, tw[3 * m]);
+        }
+        const double2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3);
+        double2 a3 = csub(v1, v3);
+        a3 = make_double2(a3.y, -a3.x);   // * (-i)
+        const int j0 = ((j - k) << 2) + k;
+        out[j0] = cadd(a0, a2);
+        out[j0 + NS] = cadd(a1, a3);
+        out[j0 + 2 * NS] = csub(a0, a2);
+        out[j0 + 3 * NS] = csub(a1, a3);
+    }
+}
+
+__device__ __forceinline__ void fft_pass_r2_last(const double2 *__restrict__ in, double2 *__restrict__ out,
+                                                 const double2 *__restrict__ tw, int tid) {
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const int j = tid + jj * 256;   // 0..1023, Ns = 1024 -> k = j, j0 = j
+        const double2 v0 = in[j];
+        const double2 v1 = cmul(in[j + 1024], tw[j]);
+        out[j] = cadd(v0, v1);
+        out[j + 1024] = csub(v0, v1);
+    }
+}
+
+__device__ __forceinline__ void fft2048(double2 *a, double2 *b, const double2 *__restrict__ tw, int tid) {
+    fft_pass_r4<1>(a, b, tw, tid);   __syncthreads();
+    fft_pass_r4<4>(b, a, tw, tid);   __syncthreads();
+    fft_pass_r4<16>(a, b, tw, tid);  __syncthreads();
+    fft_pass_r4<64>(b, a, tw, tid);  __syncthreads();
+    fft_pass_r4<256>(a, b, tw, tid); __syncthreads();
+    fft_pass_r2_last(b, a, tw, tid); __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 1: one frame per 256-thread workgroup.
+//   * loads the centred frame (zero padded at the clip edges) with coalesced reads
+//   * RMS in NumPy's float32 pairwise-summation order (bit-exact with np.mean)
+//   * packed FFT of (frame, reversed half frame) -> spectrum product -> inverse FFT
+//     = the autocorrelation acf[tau] = sum_{j=1..1024} x[j] x[j+tau], tau <= max_period
+//   * Hann-windowed FFT -> |X|^2 (rounded through complex64 like librosa.stft) -> mel
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_fft_kernel(PassParams p, DevTables tb) {
+    __shared__ double2 bufA[2048];
+    __shared__ double2 bufB[2048];
+    __shared__ float xs[2048];
+    __shared__ float pw[1032];
+    __shared__ float red[128];
+    __shared__ float blk[16];
+    __shared__ unsigned smax;
+
+    const int tid = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int c = find_clip(p.frame_off, p.n_clips, f);
+    const int64_t t = f - p.frame_off[c];
+    const int64_t base = p.sample_off[c];
+    const int64_t n = p.sample_off[c + 1] - base;
+    const int64_t start = t * p.hop - 1024;
+
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int i = tid + r * 256;
+        const int64_t idx = start + i;
+        xs[i] = (idx >= 0 && idx < n) ? p.pcm[base + idx] : 0.0f;
+    }
+    if (tid == 0) smax = 0u;
+    __syncthreads();
+
+    // ---- feature.rms: np.mean(np.square(x), axis=-2) then sqrt, float32 ----------------------
+    if ((p.stages & 0x8u) && p.out_rms != nullptr) {
+        if (tid < 128) {
+            const int bb = tid >> 3, a = tid & 7;
+            const float *xb = xs + bb * 128 + a;
+            float r = xb[0] * xb[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) { const float v = xb[8 * i]; r = r + v * v; }
+            red[tid] = r;
+        }
+        __syncthreads();
+        if (tid < 16) {
+            const float *r = red + tid * 8;
+            blk[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        }
+        __syncthreads();
+        if (tid == 0) {
+            float b0 = (blk[0] + blk[1]) + (blk[2] + blk[3]);
+            float b1 = (blk[4] + blk[5]) + (blk[6] + blk[7]);
+            float b2 = (blk[8] + blk[9]) + (blk[10] + blk[11]);
+            float b3 = (blk[12] + blk[13]) + (blk[14] + blk[15]);
+            const float total = 0.0f + ((b0 + b1) + (b2 + b3));
+            p.out_rms[f] = sqrtf(total / 2048.0f);
+        }
+    }
+
+    // ---- pYIN autocorrelation via one packed forward FFT and one inverse FFT -----------------
+    if (p.stages & 0x4u) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = tid + r * 256;
+            bufA[i] = make_double2((double)xs[i], i < 1024 ? (double)xs[1024 - i] : 0.0);
+        }
+        __syncthreads();
+        fft2048(bufA, bufB, tb.twiddle, tid);
+        // Z = FFT(x + i b):  A = (Z[k] + conj Z[N-k]) / 2,  B = (Z[k] - conj Z[N-k]) / 2i,
+        // P = A*B.  bufB receives conj(Q) where Q is the Hermitian extension of P, so that
+        // Re(FFT(conj Q)) / N is the inverse transform.
+        for (int k = tid; k <= 1024; k += 256) {
+            const double2 zk = bufA[k], zn = bufA[(2048 - k) & 2047];
+            const double2 A = make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
+            const double2 Bv = make_double2((zk.y + zn.y) * 0.5, (zn.x - zk.x) * 0.5);
+            const double2 P = cmul(A, Bv);
+            bufB[k] = make_double2(P.x, -P.y);
+            if (k > 0 && k < 1024) bufB[2048 - k] = P;
+        }
+        __syncthreads();
+        fft2048(bufB, bufA, tb.twiddle, tid);
+        double *acf = p.acf + f * (int64_t)p.lag_stride;
+        for (int tau = tid; tau <= p.max_period; tau += 256) acf[tau] = bufB[1024 + tau].x * (1.0 / 2048.0);
+        __syncthreads();
+    }
+
+    // ---- melspectrogram: Hann window (float64) -> FFT -> complex64 -> |.|^2 -> Slaney mel -----
+    if (p.stages & 0x3u) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int i = tid + r * 256;
+            bufA[i] = make_double2(tb.hann[i] * (double)xs[i], 0.0);
+        }
+        __syncthreads();
+        fft2048(bufA, bufB, tb.twiddle, tid);
+        for (int k = tid; k <= 1024; k += 256) {
+            const float re = (float)bufA[k].x, im = (float)bufA[k].y;
+            const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
+            pw[k] = mag * mag;
+        }
+        __syncthreads();
+        if (tid < p.n_mels) {
+            const int s0 = tb.mel_start[tid], len = tb.mel_len[tid];
+            const float *w = tb.mel_w + tb.mel_off[tid];
+            float acc = 0.0f;
+            for (int i = 0; i < len; ++i) acc = fmaf(w[i], pw[s0 + i], acc);
+            p.melpow[f * p.n_mels + tid] = acc;
+            atomicMax(&smax, __float_as_uint(acc));
+        }
+        __syncthreads();
+        if (tid == 0) atomicMax(&p.clipmax[c], smax);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 2: one frame per lane.  Everything here is sequential along the lag axis in the
+// reference (np.cumsum in float32 for the energy, in float64 for the CMND denominator), so
+// the lanes walk their own frame serially and stay bit-exact with NumPy.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
+    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (f >= p.n_frames) return;
+    const int c = find_clip(p.frame_off, p.n_clips, f);
+    const int64_t t = f - p.frame_off[c];
+    const int64_t base = p.sample_off[c];
+    const int64_t n = p.sample_off[c + 1] - base;
+    const int64_t start = t * p.hop - 1024;
+    const float *__restrict__ x = p.pcm + base;
+
+    // e_hi = cumsum(x^2)[k] for k < 1024
+    float e_hi = 0.0f;
+    for (int k = 0; k < 1024; ++k) {
+        const int64_t idx = start + k;
+        const float v = (idx >= 0 && idx < n) ? x[idx] : 0.0f;
+        const float sq = v * v;
+        e_hi = (k == 0) ? sq : e_hi + sq;
+    }
+    const double *__restrict__ acf = p.acf + f * (int64_t)p.lag_stride;
+    double *__restrict__ yin = p.yin + f * (int64_t)p.yin_stride;
+    float e_lo = 0.0f, en0 = 0.0f;
+    double cs = 0.0;
+    for (int tau = 0; tau <= p.max_period; ++tau) {
+        int64_t idx = start + 1024 + tau;
+        float v = (idx >= 0 && idx < n) ? x[idx] : 0.0f;
+        e_hi = e_hi + v * v;
+        idx = start + tau;
+        v = (idx >= 0 && idx < n) ? x[idx] : 0.0f;
+        const float sq = v * v;
+        e_lo = (tau == 0) ? sq : e_lo + sq;
+        float en = e_hi - e_lo;
+        if (fabsf(en) < 1e-6f) en = 0.0f;
+        if (tau == 0) en0 = en;
+        double a = acf[tau];
+        if (fabs(a) < 1e-6) a = 0.0;
+        const float esum = en0 + en;
+        const double d = (double)esum - 2.0 * a;
+        if (tau >= 1) cs = (tau == 1) ? d : cs + d;
+        if (tau >= p.min_period) yin[tau - p.min_period] = d / (cs / (double)tau + DBL_MIN);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 3: one frame per wave.  Troughs of the CMND, the Beta/Boltzmann threshold prior,
+// parabolic refinement, pitch-bin observation row in the log domain.
+// ------------------------------------------------------------------------------------------
+constexpr int kKMax = 512;    // troughs per frame (n_lags <= 1023)
+constexpr int kMaxRounds = 8; // kKMax / 64
+
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(v, o);
+        if (lane >= o) v += nb;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb) {
+    __shared__ double y[1024];
+    __shared__ double th[kKMax];
+    __shared__ double tp[kKMax];
+    __shared__ double row[512];
+    __shared__ int16_t ti[kKMax];
+    __shared__ int16_t tbin[kKMax];
+    __shared__ uint8_t twin[kKMax];
+
+    const int lane = threadIdx.x;
+    const int64_t f = blockIdx.x;
+    const int nl = p.n_lags, B = p.n_bins;
+    const double *__restrict__ yr = p.yin + f * (int64_t)p.yin_stride;
+    for (int i = lane; i < nl; i += 64) y[i] = yr[i];
+    for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
+    __syncthreads();
+
+    // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
+    const int CH = (nl + 63) >> 6;
+    unsigned mask = 0;
+    int cnt = 0;
+    for (int r = 0; r < CH; ++r) {
+        const int i = lane * CH + r;
+        if (i < nl) {
+            const double yi = y[i];
+            bool tr;
+            if (i == 0) tr = yi < y[1];
+            else if (i == nl - 1) tr = yi < y[i - 1];
+            else tr = (yi < y[i - 1]) && (yi <= y[i + 1]);
+            if (tr) { mask |= 1u << r; ++cnt; }
+        }
+    }
+    const int incl = wave_incl_scan(cnt, lane);
+    const int K = __shfl(incl, 63);
+    {
+        int k = incl - cnt;
+        for (int r = 0; r < CH; ++r)
+            if (mask & (1u << r)) { const int i = lane * CH + r; th[k] = y[i]; ti[k] = (int16_t)i; ++k; }
+    }
+    __syncthreads();
+
+    double vp = 0.0;
+    if (K > 0) {
+        const int rounds = (K + 63) >> 6;
+        int jk[kMaxRounds];
+        double acc[kMaxRounds];
+        int jmin = 101;
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            jk[q] = 101; acc[q] = 0.0;
+            if (q < rounds) {
+                const int k = q * 64 + lane;
+                if (k < K) {
+                    // first threshold index j with h < thresholds[j+1]; 100 when none
+                    const double h = th[k];
+                    int g;
+                    if (!(h < 1.0)) g = 100;          // thresholds[100] == 1.0 (also NaN)
+                    else if (h <= 0.0) g = 0;
+                    else g = (int)(h * 100.0);
+                    while (g < 100 && !(h < tb.thresholds[g + 1])) ++g;
+                    while (g > 0 && h < tb.thresholds[g]) --g;
+                    jk[q] = g;
+                    jmin = min(jmin, g);
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) jmin = min(jmin, __shfl_xor(jmin, o));
+
+        const unsigned long long lt_mask = (1ull << lane) - 1ull;
+        for (int j = jmin; j < 100; ++j) {
+            unsigned long long M[kMaxRounds];
+            int nj = 0;
+#pragma unroll
+            for (int q = 0; q < kMaxRounds; ++q) {
+                M[q] = 0ull;
+                if (q < rounds) { M[q] = __ballot(jk[q] <= j); nj += __popcll(M[q]); }
+            }
+            const double fact = tb.boltz_fact[nj];
+            const double bj = tb.beta_probs[j];
+            int before = 0;
+#pragma unroll
+            for (int q = 0; q < kMaxRounds; ++q) {
+                if (q < rounds) {
+                    if (jk[q] <= j) {
+                        const int pos = before + __popcll(M[q] & lt_mask);
+                        const double prior = fact * tb.boltz_exp[pos];
+                        acc[q] = fma(prior, bj, acc[q]);
+                    }
+                    before += __popcll(M[q]);
+                }
+            }
+        }
+
+        // global minimum trough (first index on ties) gets the no-trough mass
+        double bh = INFINITY;
+        int bk = kKMax;
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            const int k = q * 64 + lane;
+            if (q < rounds && k < K) { const double h = th[k]; if (h < bh) { bh = h; bk = k; } }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double oh = __shfl_xor(bh, o);
+            const int ok = __shfl_xor(bk, o);
+            if (oh < bh || (oh == bh && ok < bk)) { bh = oh; bk = ok; }
+        }
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            if (q < rounds && q * 64 + lane == bk) {
+                const int nb = jk[q] > 100 ? 100 : jk[q];
+                acc[q] = acc[q] + 0.01 * tb.beta_cumsum[nb];
+            }
+        }
+
+        // parabolic refinement and pitch bin for every trough that carries probability
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            const int k = q * 64 + lane;
+            if (q < rounds && k < K) {
+                const double pr = acc[q];
+                int bin = -1;
+                if (pr != 0.0) {
+                    const int i = ti[k];
+                    double shift = 0.0;
+                    if (i > 0 && i < nl - 1) {
+                        const double ym = y[i - 1], y0 = y[i], yp = y[i + 1];
+                        const double a = yp + ym - 2.0 * y0;
+                        const double b = (yp - ym) / 2.0;
+                        if (fabs(b) < fabs(a)) shift = -b / a;
+                    }
+                    const double period = (double)(p.min_period + i) + shift;
+                    const double f0c = (double)p.sr / period;
+                    double r = rint(120.0 * log2(f0c / p.fmin));
+                    r = r < 0.0 ? 0.0 : (r > (double)B ? (double)B : r);
+                    bin = (int)r;
+                }
+                tp[k] = pr;
+                tbin[k] = (int16_t)bin;
+            }
+        }
+        __syncthreads();
+        // observation_probs[bin, t] = probs: on duplicate bins the largest lag wins; bins are
+        // non-increasing in lag, so a trough loses exactly when the next trough with
+        // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
+#pragma unroll
+        for (int q = 0; q < kMaxRounds; ++q) {
+            const int k = q * 64 + lane;
+            if (q < rounds && k < K) {
+                const int bin = tbin[k];
+                bool win = false;
+                if (bin >= 0 && bin < B) {
+                    int k2 = k + 1;
+                    while (k2 < K && tbin[k2] < 0) ++k2;
+                    win = (k2 >= K) || (tbin[k2] != bin);
+                    if (win) row[bin] = log(tp[k] + DBL_MIN);
+                }
+                twin[k] = win ? 1 : 0;
+            }
+        }
+        __syncthreads();
+        // voiced_prob = sum over bins in increasing bin order = decreasing lag order
+        if (lane == 0) {
+            double s = 0.0;
+            for (int k = K - 1; k >= 0; --k)
+                if (twin[k]) s = s + tp[k];
+            vp = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        }
+        vp = __shfl(vp, 0);
+    }
+    __syncthreads();
+    double *__restrict__ orow = p.logobs + f * (int64_t)p.obs_stride;
+    for (int b = lane; b < B; b += 64) orow[b] = row[b];
+    if (lane == 0) {
+        const double unv = (1.0 - vp) / (double)B;
+        p.logunv[f] = log(unv + DBL_MIN);
+        if (p.out_vprob != nullptr) p.out_vprob[f] = vp;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 4: log-domain Viterbi, one workgroup per clip, one thread per HMM state.
+//
+// librosa's transition matrix is kron(loop(2, .99), local(B, width)) + tiny, dense.  A target
+// state (v', b') therefore sees 2*width in-band predecessors with distinct log-probabilities
+// and every other state at log(tiny).  Among those out-of-band predecessors only the global
+// arg-max of the previous column can win (any in-band candidate built on that arg-max beats
+// log(tiny)), so each step evaluates the band exactly and one extra candidate.  arg-max ties
+// resolve to the lowest state index, as np.argmax does.
+//
+// Back-pointers go to HBM; every kViterbiChunk steps the chunk's pointer maps are composed in
+// LDS into one map per chunk, so the final back-trace is a short serial walk over chunk maps
+// followed by a parallel walk inside the chunks.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables tb, int lt_in_lds) {
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int B = p.n_bins, S = 2 * B, H = p.half_width, W = p.width, NC = p.n_cls;
+    const int SP = (S + 63) & ~63;
+    constexpr int C = kViterbiChunk;
+    double *val = reinterpret_cast<double *>(smem_raw);   // [2][SP]
+    double *rv = val + 2 * SP;                            // [2][16]
+    int *ri = reinterpret_cast<int *>(rv + 32);           // [2][16]
+    uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [C][S]
+    double *ltl = reinterpret_cast<double *>(smem_raw + ((2 * SP + 32) * 8 + 32 * 4 + C * S * 2 + 15) / 16 * 16);
+
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+    if (lt_in_lds)
+        for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = tb.lt_band[i];
+    const double *lt = lt_in_lds ? ltl : tb.lt_band;
+
+    const int c = p.order[blockIdx.x];
+    const int64_t f0 = p.frame_off[c];
+    const int T = (int)(p.frame_off[c + 1] - f0);
+    const int os = p.obs_stride;
+    const double *__restrict__ lobs = p.logobs + f0 * os;
+    const double *__restrict__ lunv = p.logunv + f0;
+    uint16_t *__restrict__ ptr = p.ptr + f0 * S;
+    const int64_t ch0 = p.chunk_off[c];
+    uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
+    int32_t *__restrict__ bnd = p.bnd + ch0;
+    int32_t *__restrict__ states = p.states + f0;
+    const int nch = (T - 1 + C - 1) / C;
+
+    const int j = tid;
+    const bool act = j < S;
+    const int v2 = (j >= B) ? 1 : 0;
+    const int b2 = j - v2 * B;
+    const int dlo = max(0, H - b2);
+    const int dhi = min(W - 1, B - 1 - b2 + H);
+
+    double myv = -INFINITY;
+    if (act) {
+        const double lp = v2 ? lunv[0] : lobs[b2];
+        myv = lp + p.log_pinit;
+        val[j] = myv;
+    }
+    int par = 0;
+    double G;
+    int kg;
+    auto block_argmax = [&](double v, int ix) {
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            const double ov = __shfl_down(v, o);
+            const int oi = __shfl_down(ix, o);
+            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
+        }
+        if (lane == 0) { rv[par * 16 + wid] = v; ri[par * 16 + wid] = ix; }
+        __syncthreads();
+        G = rv[par * 16]; kg = ri[par * 16];
+        for (int w = 1; w < nw; ++w) {
+            const double ov = rv[par * 16 + w];
+            const int oi = ri[par * 16 + w];
+            if (ov > G || (ov == G && oi < kg)) { G = ov; kg = oi; }
+        }
+        par ^= 1;
+    };
+    block_argmax(myv, act ? j : 0x7fffffff);
+
+    double *cur = val, *nxt = val + SP;
+    for (int t = 1; t < T; ++t) {
+        double lp = 0.0;
+        if (act) lp = v2 ? lunv[t] : lobs[(int64_t)t * os + b2];
+        double best = -INFINITY;
+        int bi = 0;
+        if (act) {
+#pragma unroll
+            for (int v = 0; v < 2; ++v) {
+                const double *cv = cur + v * B;
+                const double *ltv = lt + (size_t)(v * 2 + v2) * NC * W;
+                for (int d = dlo; d <= dhi; ++d) {
+                    const int b = b2 + d - H;
+                    const int cl = b < H ? b : (b > B - 1 - H ? b - (B - 1 - 2 * H) : H);
+                    const double cand = cv[b] + ltv[cl * W + (W - 1 - d)];
+                    if (cand > best) { best = cand; bi = v * B + b; }
+                }
+            }
+            const int bg = kg >= B ? kg - B : kg;
+            const int dist = bg > b2 ? bg - b2 : b2 - bg;
+            if (dist > H) {
+                const double cand = G + p.log_tiny;
+                if (cand > best || (cand == best && kg < bi)) { best = cand; bi = kg; }
+            }
+            myv = lp + best;
+            nxt[j] = myv;
+            ring[((t - 1) % C) * S + j] = (uint16_t)bi;
+            ptr[(int64_t)t * S + j] = (uint16_t)bi;
+        }
+        block_argmax(myv, act ? j : 0x7fffffff);
+        double *tmp = cur; cur = nxt; nxt = tmp;
+        if (t % C == 0 || t == T - 1) {
+            const int cc = (t - 1) / C;
+            if (act) {
+                int s = j;
+                for (int tt = t; tt > cc * C; --tt) s = ring[((tt - 1) % C) * S + s];
+                cmap[(int64_t)cc * S + j] = (uint16_t)s;
+            }
+            __syncthreads();
+        }
+    }
+
+    // back-trace: serial over chunk maps, then parallel inside the chunks
+    if (tid == 0) {
+        int s = kg;
+        for (int cc = nch - 1; cc >= 0; --cc) { bnd[cc] = s; s = cmap[(int64_t)cc * S + s]; }
+        states[0] = s;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int cc = tid; cc < nch; cc += nthr) {
+        const int te = min((cc + 1) * C, T - 1);
+        int s = bnd[cc];
+        states[te] = s;
+        for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 5a: f0 / voiced decode (pitch.py: f0 = freqs[state % B], voiced = state < B).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_kernel(PassParams p, DevTables tb) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= p.n_frames) return;
+    const int s = p.states[f];
+    const bool voiced = s < p.n_bins;
+    if (p.out_voiced != nullptr) p.out_voiced[f] = voiced ? 1 : 0;
+    if (p.out_f0 != nullptr) p.out_f0[f] = voiced ? tb.freqs[s] : (double)NAN;
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 5b: power_to_db(ref=np.max, top_db=80) per clip, the per-column broadband test of
+// vision.py:11-21, and the [F][n_mels] -> [n_mels][F] transpose of the dB image through LDS.
+// 64 frames per workgroup; wave w owns rows w*16 .. w*16+15.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void db_rake_kernel(PassParams p) {
+    __shared__ float tile[64][129];
+    __shared__ int rclip[64];
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int nm = p.n_mels;
+    const int64_t fb = (int64_t)blockIdx.x * 64;
+    for (int rr = 0; rr < 16; ++rr) {
+        const int r = wid * 16 + rr;
+        const int64_t f = fb + r;
+        if (f >= p.n_frames) { if (lane == 0) rclip[r] = -1; continue; }
+        const int c = find_clip(p.frame_off, p.n_clips, f);
+        if (lane == 0) rclip[r] = c;
+        const float ref = fmaxf(1e-10f, __uint_as_float(p.clipmax[c]));
+        const float refdb = 10.0f * (float)log10((double)ref);
+        float cmax = -INFINITY;
+        for (int m = lane; m < nm; m += 64) {
+            const float s = fmaxf(1e-10f, p.melpow[f * nm + m]);
+            float v = 10.0f * (float)log10((double)s);
+            v = v - refdb;
+            v = fmaxf(v, 0.0f - 80.0f);
+            tile[r][m] = v;
+            cmax = fmaxf(cmax, v);
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) cmax = fmaxf(cmax, __shfl_xor(cmax, o));
+        int active = 0;
+        const float thr = cmax - 20.0f;
+        for (int m0 = 0; m0 < nm; m0 += 64) {
+            const int m = m0 + lane;
+            const bool on = (m < nm) && (tile[r][m] > thr);
+            active += __popcll(__ballot(on));
+        }
+        if (lane == 0) {
+            bool cand = false;
+            if (!(cmax < -60.0f)) cand = ((double)active / (double)nm) > p.rake_ratio;
+            p.rake_raw[f] = cand ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (p.out_sdb != nullptr) {
+        for (int idx = tid; idx < 64 * nm; idx += 256) {
+            const int m = idx >> 6, r = idx & 63;
+            const int c = rclip[r];
+            if (c < 0) continue;
+            const int64_t fo = p.frame_off[c];
+            const int64_t Fc = p.frame_off[c + 1] - fo;
+            const int64_t tl = fb + r - fo;
+            p.out_sdb[(int64_t)nm * fo + (int64_t)m * Fc + tl] = tile[r][m];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Kernel 5c: run-length filter of vision.py:27-36.  A candidate frame survives when its run
+// is closed before the end of the clip and min_frames <= length <= max_frames.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rake_runs_kernel(PassParams p) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= p.n_frames || p.out_rake == nullptr) return;
+    uint8_t keep = 0;
+    if (p.rake_raw[f]) {
+        const int c = find_clip(p.frame_off, p.n_clips, f);
+        const int64_t lo = p.frame_off[c], hi = p.frame_off[c + 1];
+        const int lim = p.rake_max_frames + 1;
+        int64_t s = f, e = f + 1;
+        int steps = 0;
+        while (s > lo && p.rake_raw[s - 1] && steps <= lim) { --s; ++steps; }
+        while (e < hi && p.rake_raw[e] && steps <= lim) { ++e; ++steps; }
+        const int64_t len = e - s;
+        const bool closed = e < hi;   // a run still open at the end of the clip is dropped
+        if (steps <= lim && closed && len >= p.rake_min_frames && len <= p.rake_max_frames) keep = 1;
+    }
+    p.out_rake[f] = keep;
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
+    const int S = 2 * p.n_bins, SP = (S + 63) & ~63;
+    size_t b = ((size_t)(2 * SP + 32) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16 * 16;
+    if (with_lt) b += (size_t)4 * p.n_cls * p.width * 8;
+    return b;
+}
+
+hipError_t viterbi_configure() {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
+    if (p.n_frames == 0 || !(p.stages & 0xFu)) return;
+    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)p.n_frames), dim3(256), 0, s, p, t);
+}
+void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
+    if (p.n_frames == 0) return;
+    hipLaunchKernelGGL(yin_seq_kernel, dim3((unsigned)((p.n_frames + 63) / 64)), dim3(64), 0, s, p);
+}
+void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
+    if (p.n_frames == 0) return;
+    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_frames), dim3(64), 0, s, p, t);
+}
+hipError_t launch_viterbi(const PassParams &p, const DevTables &t, hipStream_t s) {
+    if (p.n_clips == 0) return hipSuccess;
+    const int S = 2 * p.n_bins;
+    const int nthr = (S + 63) & ~63;
+    const bool with_lt = viterbi_lds_bytes(p, true) <= 160 * 1024;
+    const size_t lds = viterbi_lds_bytes(p, with_lt);
+    if (nthr > 1024 || lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)p.n_clips), dim3(nthr), lds, s, p, t, with_lt ? 1 : 0);
+    return hipGetLastError();
+}
+void launch_finalize(const PassParams &p, const DevTables &t, hipStream_t s) {
+    if (p.n_frames == 0) return;
+    const unsigned g256 = (unsigned)((p.n_frames + 255) / 256);
+    if (p.stages & 0x4u) hipLaunchKernelGGL(decode_kernel, dim3(g256), dim3(256), 0, s, p, t);
+    if (p.stages & 0x3u) {
+        hipLaunchKernelGGL(db_rake_kernel, dim3((unsigned)((p.n_frames + 63) / 64)), dim3(256), 0, s, p);
+        if (p.stages & 0x2u) hipLaunchKernelGGL(rake_runs_kernel, dim3(g256), dim3(256), 0, s, p);
+    }
+}
+
+}  // namespace aegis
