@@ -96,6 +96,12 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
                                int32_t n_clips, double rake_sensitivity, uint32_t stages,
                                aegis_outputs *device_out, void *stream, int32_t sync);
 
+/* AegisEngine.detect_rake_patterns(S_dB) (aegis_engine.py:38-39 -> vision.py:3-38) on a
+ * caller-supplied dB image in host memory, [n_mels, n_frames] C-order; mask_out is
+ * uint8[n_frames] in host memory.  Blocking. */
+int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int64_t n_frames,
+                        double broadband_threshold_ratio, uint8_t *mask_out);
+
 /* --- introspection used by the tests (no reference counterpart) ------------- */
 
 /* Host-side copies of the tables the kernels use.  `name` is one of

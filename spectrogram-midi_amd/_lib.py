@@ -31,7 +31,7 @@ class Outputs(C.Structure):
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
-           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms")
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns")
 
 _lib = None
 
@@ -61,6 +61,8 @@ def load():
     lib.aegis_analyze_batch_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32,
                                                C.c_double, C.c_uint32, C.POINTER(Outputs), C.c_void_p, C.c_int32]
     lib.aegis_analyze_batch_device.restype = C.c_int
+    lib.aegis_rake_patterns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_void_p]
+    lib.aegis_rake_patterns.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_get_table.restype = C.c_int64
     lib.aegis_get_param.argtypes = [C.c_void_p, C.c_char_p]
@@ -180,6 +182,13 @@ class Handle:
             res.append(d)
             fo += Fc
         return res
+
+    def rake_patterns(self, S_dB, ratio):
+        S = np.ascontiguousarray(S_dB, dtype=np.float32)
+        n_mels, F = S.shape
+        out = np.zeros(F, np.uint8)
+        self._check(self.lib.aegis_rake_patterns(self._h, S.ctypes.data, n_mels, F, float(ratio), out.ctypes.data))
+        return out.astype(bool)
 
     def analyze_batch_device(self, d_pcm_ptr, sample_offsets, outputs, rake_sensitivity=0.6,
                              stages=STAGE_ALL, stream=None, sync=True):

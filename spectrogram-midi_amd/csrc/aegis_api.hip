@@ -407,6 +407,30 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     return AEGIS_OK;
 }
 
+int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int64_t n_frames,
+                        double broadband_threshold_ratio, uint8_t *mask_out) {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_mels <= 0 || n_frames < 0 || (n_frames > 0 && (!S_dB || !mask_out))) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
+    if (n_frames == 0) return AEGIS_OK;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc;
+    const size_t img = (size_t)n_mels * n_frames * 4;
+    if ((rc = ensure(h, h->io_sdb, img)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->rake_raw, n_frames)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->io_rake, n_frames)) != AEGIS_OK) return rc;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipMemcpyAsync(h->io_sdb.p, S_dB, img, hipMemcpyHostToDevice, s));
+    const double ms_per_frame = ((double)h->tab.hop / (double)h->tab.sr) * 1000;   // vision.py:23-25
+    launch_rake_from_db(static_cast<const float *>(h->io_sdb.p), n_mels, n_frames, broadband_threshold_ratio,
+                        (int)(10 / ms_per_frame), (int)(30 / ms_per_frame), static_cast<uint8_t *>(h->rake_raw.p),
+                        static_cast<uint8_t *>(h->io_rake.p), s);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(mask_out, h->io_rake.p, n_frames, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return AEGIS_OK;
+}
+
 int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (!h || !name) return AEGIS_ERR_INVALID;
     const Tables &t = h->tab;

@@ -675,6 +675,52 @@ __global__ __launch_bounds__(256) void rake_runs_kernel(PassParams p) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Stand-alone rake detection on a caller-supplied dB image [n_mels][F] (the reference's
+// AegisEngine.detect_rake_patterns(S_dB), aegis_engine.py:38-39): column test + run filter.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rake_cols_kernel(const float *__restrict__ sdb, int n_mels, int64_t F,
+                                                        double ratio, uint8_t *__restrict__ raw) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= F) return;
+    float cmax = -INFINITY;
+    for (int m = 0; m < n_mels; ++m) cmax = fmaxf(cmax, sdb[(int64_t)m * F + t]);
+    bool cand = false;
+    if (!(cmax < -60.0f)) {
+        const float thr = cmax - 20.0f;
+        int active = 0;
+        for (int m = 0; m < n_mels; ++m) active += sdb[(int64_t)m * F + t] > thr ? 1 : 0;
+        cand = ((double)active / (double)n_mels) > ratio;
+    }
+    raw[t] = cand ? 1 : 0;
+}
+
+__global__ __launch_bounds__(256) void rake_runs_simple_kernel(const uint8_t *__restrict__ raw, int64_t F,
+                                                               int min_frames, int max_frames,
+                                                               uint8_t *__restrict__ out) {
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= F) return;
+    uint8_t keep = 0;
+    if (raw[f]) {
+        const int lim = max_frames + 1;
+        int64_t s = f, e = f + 1;
+        int steps = 0;
+        while (s > 0 && raw[s - 1] && steps <= lim) { --s; ++steps; }
+        while (e < F && raw[e] && steps <= lim) { ++e; ++steps; }
+        const int64_t len = e - s;
+        if (steps <= lim && e < F && len >= min_frames && len <= max_frames) keep = 1;
+    }
+    out[f] = keep;
+}
+
+void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, int min_frames, int max_frames,
+                         uint8_t *raw, uint8_t *out, hipStream_t s) {
+    if (F == 0) return;
+    const unsigned g = (unsigned)((F + 255) / 256);
+    hipLaunchKernelGGL(rake_cols_kernel, dim3(g), dim3(256), 0, s, sdb, n_mels, F, ratio, raw);
+    hipLaunchKernelGGL(rake_runs_simple_kernel, dim3(g), dim3(256), 0, s, raw, F, min_frames, max_frames, out);
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
 static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {

@@ -1,0 +1,181 @@
+"""`AegisEngine`: the reference's engine facade (/root/reference/aegis_engine.py:16-216) over
+the MI355X kernels.  Same constructor, method names, keyword arguments, return types and error
+behaviour, so the Streamlit/FastAPI callers and midi_logic consume it unchanged:
+
+    engine = AegisEngine()                       # aegis_engine.py:17
+    raw = engine.audio_to_midi(wav, None, turbo_mode=True, rake_sensitivity=0.6)   # :41-75
+    events = engine.extract_events(raw, "out.mid", confidence_threshold=0.7)        # :77-181
+
+The per-frame arithmetic (mel/dB/rake, pYIN, RMS) runs in libaegis_hip.so; there is no CPU
+path -- without the extension or a GPU every analyze call raises.
+"""
+import multiprocessing
+
+import numpy as np
+
+from . import _lib, audio_io, midi_logic, smf
+from .convert import note_to_hz
+
+_FMIN, _FMAX = note_to_hz("E2"), note_to_hz("C6")
+_ENGINE_ONLY_KWARGS = ("confidence_threshold", "start_time", "end_time", "turbo_mode", "rake_sensitivity",
+                       "vibrato_rate", "vibrato_depth")
+
+
+def _require_finite(y):
+    if not np.isfinite(y).all():      # librosa.util.valid_audio raises ParameterError here
+        raise ValueError("Audio buffer is not finite everywhere")
+
+
+class AegisEngine:
+    def __init__(self, sample_rate=44100, hop_length=512, n_fft=2048, device=0, verbose=False):
+        self.sr = sample_rate
+        self.hop_length = hop_length
+        self.n_fft = n_fft
+        self.device = device
+        self.verbose = verbose
+        self.turbo_cores = None      # None -> multiprocessing.cpu_count(), as aegis_engine.py:187
+        self._handle = None
+
+    # ------------------------------------------------------------------ device context
+    @property
+    def handle(self):
+        if self._handle is None:
+            self._handle = _lib.Handle(sample_rate=self.sr, hop_length=self.hop_length, n_fft=self.n_fft,
+                                       n_mels=128, fmin=_FMIN, fmax=_FMAX, device=self.device)
+        return self._handle
+
+    def close(self):
+        if self._handle is not None:
+            self._handle.close()
+            self._handle = None
+
+    def _say(self, msg):
+        if self.verbose:
+            print(msg)
+
+    # ------------------------------------------------------------------ reference surface
+    def load_audio(self, file_path, start_time=0, end_time=None):
+        """-> (y float32[N], S_dB float32[128, F])  (aegis_engine.py:22-27)."""
+        duration = (end_time - start_time) if end_time else None
+        y = audio_io.read_wav(file_path, self.sr, offset=start_time, duration=duration)
+        _require_finite(y)
+        out = self.handle.analyze_batch([y], stages=_lib.STAGE_MEL)[0]
+        return y, out["S_dB"]
+
+    def detect_rake_patterns(self, S_dB):
+        """aegis_engine.py:38-39 (fixed 0.6 ratio)."""
+        return self.handle.rake_patterns(S_dB, 0.6)
+
+    def separate_stems(self, input_wav, output_dir):
+        raise NotImplementedError("stem separation shells out to demucs in the reference "
+                                  "(aegis_engine_core/stems.py); outside the MI355X analyze path")
+
+    def generate_tabs(self, events):
+        raise NotImplementedError("tab generation (aegis_engine_core/tabs.py) consumes the event list "
+                                  "unchanged; outside the MI355X analyze path")
+
+    def export_musicxml(self, tab_data, xml_path):
+        raise NotImplementedError("MusicXML export (aegis_engine_core/tabs.py) is outside the MI355X analyze path")
+
+    def audio_to_midi(self, input_wav, output_mid, **kwargs):
+        """Perception phase -> raw_data dict or None for empty audio (aegis_engine.py:41-75).
+        `output_mid` is accepted and ignored, as in the reference."""
+        start_time, end_time = kwargs.get("start_time", 0), kwargs.get("end_time", None)
+        duration = (end_time - start_time) if end_time else None
+        y = audio_io.read_wav(input_wav, self.sr, offset=start_time, duration=duration)
+        return self.analyze_array(y, turbo_mode=kwargs.get("turbo_mode", False),
+                                  rake_sensitivity=kwargs.get("rake_sensitivity", 0.6))
+
+    analyze = audio_to_midi      # BASELINE.json's name for the same call
+
+    def analyze_array(self, y, turbo_mode=False, rake_sensitivity=0.6):
+        """audio_to_midi from decoded PCM onward (aegis_engine.py:51-75)."""
+        res = self.analyze_arrays([y], turbo_mode=turbo_mode, rake_sensitivity=rake_sensitivity)
+        return res[0]
+
+    def analyze_arrays(self, clips, turbo_mode=False, rake_sensitivity=0.6):
+        """Batch form: one ragged GPU batch for a folder of clips; element i is what
+        audio_to_midi returns for clip i (None for an empty clip)."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        live = [i for i, c in enumerate(clips) if len(c) > 0]
+        for i in live:
+            _require_finite(clips[i])
+        results = [None] * len(clips)
+        if not live:
+            return results
+        self._say(f"[Aegis] Starting Perception Phase (Turbo: {turbo_mode})...")
+        h = self.handle
+        if turbo_mode:
+            frames = h.analyze_batch([clips[i] for i in live], rake_sensitivity=rake_sensitivity,
+                                     stages=_lib.STAGE_MEL | _lib.STAGE_RAKE | _lib.STAGE_RMS, want_sdb=False)
+            for i, r in zip(live, frames):
+                try:
+                    r["f0"], r["voiced_flag"], r["voiced_prob"] = self._parallel_pitch_tracking(clips[i])
+                except _lib.AegisError:
+                    raise
+                except Exception as e:    # aegis_engine.py:61-63: fall back to the stable path
+                    self._say(f"[Aegis] Parallel failed ({e}), falling back to stable core.")
+                    p = h.analyze_batch([clips[i]], stages=_lib.STAGE_PYIN)[0]
+                    r["f0"], r["voiced_flag"], r["voiced_prob"] = p["f0"], p["voiced_flag"], p["voiced_prob"]
+        else:
+            self._say("[Aegis] Using Stable Single-core Analysis.")
+            frames = h.analyze_batch([clips[i] for i in live], rake_sensitivity=rake_sensitivity,
+                                     stages=_lib.STAGE_ALL, want_sdb=False)
+        for i, r in zip(live, frames):
+            results[i] = {"rake_mask": r["rake_mask"], "f0": np.nan_to_num(r["f0"]),
+                          "voiced_flag": r["voiced_flag"], "voiced_probs": r["voiced_prob"],
+                          "rms": r["rms"], "y": clips[i]}
+        return results
+
+    def extract_events(self, raw_data, output_mid, **kwargs):
+        """Logic filter layer (aegis_engine.py:77-181): raw_data -> events, optional SMF to a
+        path or a file-like object."""
+        keys = ("rake_mask", "f0", "voiced_flag", "voiced_probs", "rms")
+        n = min(len(raw_data["rake_mask"]), len(raw_data["f0"]), len(raw_data["rms"]))
+        rake_mask, f0, voiced_flag, voiced_probs, rms = (raw_data[k][:n] for k in keys)
+        passthrough = {k: v for k, v in kwargs.items() if k not in _ENGINE_ONLY_KWARGS}
+        events = midi_logic.get_midi_events(
+            rake_mask=rake_mask, f0=f0, voiced_flag=voiced_flag, active_probs=voiced_probs, rms=rms,
+            sr=self.sr, hop_length=self.hop_length,
+            confidence_threshold=kwargs.get("confidence_threshold", 0.70), **passthrough)
+        if output_mid:
+            blob = smf.render(events, self.sr, self.hop_length, midi_program=kwargs.get("midi_program", 27),
+                              vibrato_rate=kwargs.get("vibrato_rate", 5.0),
+                              vibrato_depth=kwargs.get("vibrato_depth", 0.3))
+            if hasattr(output_mid, "write"):
+                output_mid.write(blob)
+            else:
+                with open(output_mid, "wb") as f:
+                    f.write(blob)
+        return events
+
+    # ------------------------------------------------------------------ Turbo Mode
+    def _turbo_spans(self, n_samples):
+        """Equal frame spans per core, last one takes the remainder (aegis_engine.py:192-204)."""
+        cores = self.turbo_cores or multiprocessing.cpu_count()
+        total = int(np.ceil(n_samples / self.hop_length))
+        per = total // cores or total
+        spans = []
+        for i in range(cores):
+            lo = i * per
+            if lo >= total:
+                break
+            hi = (i + 1) * per if i < cores - 1 else total
+            a, b = lo * self.hop_length, min(hi * self.hop_length, n_samples)
+            if b > a:
+                spans.append((a, b))
+        return spans
+
+    def _parallel_pitch_tracking(self, y):
+        """Turbo Mode (aegis_engine.py:183-216): the clip is cut into cpu_count() time chunks,
+        each chunk is pYIN-tracked on its own (own centring, own Viterbi) and the results are
+        concatenated.  The reference maps chunks over a process pool; here they are the clips of
+        one GPU batch, so every chunk's Viterbi runs on its own compute unit concurrently."""
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        h = self.handle
+        if len(y) / self.sr < 5.0:
+            r = h.analyze_batch([y], stages=_lib.STAGE_PYIN)[0]
+            return r["f0"], r["voiced_flag"], r["voiced_prob"]
+        parts = h.analyze_batch([y[a:b] for a, b in self._turbo_spans(len(y))], stages=_lib.STAGE_PYIN)
+        return (np.concatenate([p["f0"] for p in parts]), np.concatenate([p["voiced_flag"] for p in parts]),
+                np.concatenate([p["voiced_prob"] for p in parts]))
