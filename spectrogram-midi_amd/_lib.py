@@ -6,7 +6,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaegis_hip.so")
+LIB_PATH = os.environ.get("AEGIS_HIP_LIB", os.path.join(_HERE, "libaegis_hip.so"))
 
 STAGE_MEL, STAGE_RAKE, STAGE_PYIN, STAGE_RMS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95

@@ -343,7 +343,7 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
             begin_event(h, "yin_seq", s); launch_yin_seq(p, h->dt, s); end_event(h, s);
             begin_event(h, "pyin_obs", s); launch_pyin_obs(p, h->dt, s); end_event(h, s);
             begin_event(h, "viterbi", s);
-            hipError_t ve = launch_viterbi(p, h->dt, s);
+            hipError_t ve = launch_viterbi(p, h->dt, t.log_trans_band.data(), s);
             end_event(h, s);
             if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
         }

@@ -64,7 +64,7 @@ constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
 void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_yin_seq(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
-hipError_t launch_viterbi(const PassParams &p, const DevTables &t, hipStream_t s);
+hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
 void launch_finalize(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, int min_frames, int max_frames,
                          uint8_t *raw, uint8_t *out, hipStream_t s);

@@ -15,6 +15,7 @@
 
 #include <cfloat>
 #include <cmath>
+#include <cstring>
 
 namespace aegis {
 
@@ -583,6 +584,275 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
 }
 
 // ------------------------------------------------------------------------------------------
+// Kernel 4 (band-specialised): the same recurrence with the half width H known at compile
+// time.  Thread layout: two voicing halves of BP = roundup(B, 64) threads, so the target's
+// voicing v' is wave-uniform.  Sources are split by the class of their transition row:
+//   * interior rows (H <= b <= B-1-H) all share one 4 x (2H+1) table: the values live in a
+//     -inf padded LDS array, the 2(2H+1) candidates are a fully unrolled loop of
+//     ds_read_b64 (immediate offset) + v_add_f64 with a scalar table operand + compare/select;
+//   * edge rows (b < H or b > B-1-H) are row-normalised differently: only waves within reach
+//     of an edge walk them, one source at a time (source uniform, table lookup per lane).
+// Candidate order does not matter for the result: ties are resolved explicitly to the lowest
+// state index wherever the evaluation order is not the index order.
+// ------------------------------------------------------------------------------------------
+// wave64 max of a double via DPP row shifts / row broadcasts (result valid in lane 63)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_fmax(double v) {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return fmax(v, __hiloint2double(hi2, lo2));
+}
+__device__ __forceinline__ double row16_prefix_max(double v) {   // lane 15 of each row = row max
+    v = dpp_fmax<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_fmax<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_fmax<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_fmax<0x118, 0xf>(v);   // row_shr:8
+    return v;
+}
+__device__ __forceinline__ double read_lane_f64(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
+                            __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Interior-row log-transition table, passed BY VALUE: kernel arguments live in the kernarg
+// segment, which the compiler reads with scalar loads (s_load_dwordx16) -- the 2(2H+1) table
+// operands of a step then sit in SGPRs and cost no vector memory traffic or VGPRs.
+template <int H>
+struct BandLT {
+    double v[4][2 * H + 1];   // [v*2+v'][dd]
+};
+
+template <int H, bool LT_LDS>
+__global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTables tb, BandLT<H> blt) {
+    constexpr int W = 2 * H + 1;
+    constexpr int C = kViterbiChunk;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int B = p.n_bins, S = 2 * B, NC = p.n_cls;
+    const int BP = (B + 63) & ~63;
+    const int PADB = (B + 2 * H + 64 + 7) & ~7;            // slack: inactive lanes read past B+2H
+    double *valI = reinterpret_cast<double *>(smem_raw);   // [2 buf][2 v][PADB], index b + H
+    double *valE = valI + 4 * PADB;                        // [2 buf][2 v][2H]
+    double *rv = valE + 8 * H;                             // [2][16]
+    int *ri = reinterpret_cast<int *>(rv + 32);            // [2][16]
+    uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [C][S]
+    double *ltl = reinterpret_cast<double *>(
+        smem_raw + (((size_t)(4 * PADB + 8 * H + 32) * 8 + 32 * 4 + (size_t)C * S * 2 + 15) / 16) * 16);
+
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
+    const int vp = __builtin_amdgcn_readfirstlane(tid >= BP ? 1 : 0);
+    const int b2 = tid - vp * BP;
+    const bool act = b2 < B;
+    const int b2c = act ? b2 : 0;
+    const int j = vp * B + b2c;
+    const int wlo = __builtin_amdgcn_readfirstlane(b2 - lane), whi = wlo + 63;
+    const bool wave_low = wlo < 2 * H;            // some target of this wave sees low-edge sources
+    const bool wave_high = whi >= B - 2 * H;      // ... high-edge sources (never both: B >= 4H+128)
+    const bool is_low = b2c < H, is_high = b2c > B - 1 - H;
+    const int eidx = is_low ? b2c : b2c - B + 2 * H;
+
+    for (int i = tid; i < 4 * PADB + 8 * H; i += nthr) valI[i] = -INFINITY;
+    // edge-row table: LDS copy of the band table; the (unused here) interior row of each
+    // (v,v') block donates its first slot as a -inf sentinel for out-of-reach (lane, source) pairs
+    const double *lt_e0;   // block (v = 0, v' = vp); the v = 1 block sits 2*NC*W further
+    if (LT_LDS) {
+        for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = (i % (NC * W) == H * W) ? -INFINITY : tb.lt_band[i];
+        lt_e0 = ltl + (size_t)vp * NC * W;
+    } else {
+        lt_e0 = tb.lt_band + (size_t)vp * NC * W;
+    }
+    const double *lti0 = blt.v[0 * 2 + vp];   // interior row, source v = 0, target v' = vp
+    const double *lti1 = blt.v[1 * 2 + vp];   // source v = 1
+    constexpr int kSentinel = H * W;
+
+    const int c = p.order[blockIdx.x];
+    const int64_t f0 = p.frame_off[c];
+    const int T = (int)(p.frame_off[c + 1] - f0);
+    const int os = p.obs_stride;
+    const double *__restrict__ lobs = p.logobs + f0 * os;
+    const double *__restrict__ lunv = p.logunv + f0;
+    uint16_t *__restrict__ ptr = p.ptr + f0 * S;
+    const int64_t ch0 = p.chunk_off[c];
+    uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
+    int32_t *__restrict__ bnd = p.bnd + ch0;
+    int32_t *__restrict__ states = p.states + f0;
+    const int nch = (T - 1 + C - 1) / C;
+    __syncthreads();
+
+    auto store_value = [&](int buf, double v) {
+        if (is_low || is_high) valE[(buf * 2 + vp) * 2 * H + eidx] = v;
+        else valI[(buf * 2 + vp) * PADB + b2c + H] = v;
+    };
+
+    double myv = -INFINITY;
+    if (act) {
+        const double lp = vp ? lunv[0] : lobs[b2c];
+        myv = lp + p.log_pinit;
+        store_value(0, myv);
+    }
+    int par = 0;
+    double G;
+    int kg;
+    // block arg-max (lowest index on ties): DPP wave max -> first lane holding it -> one LDS slot
+    // per wave -> every wave reduces the <=16 slots the same way.  Waves and lanes are in state order.
+    auto block_argmax = [&](double v) {
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 2)
+        __syncthreads(); G = v; kg = 0; return;
+#endif
+        double m = row16_prefix_max(v);
+        m = dpp_fmax<0x142, 0xa>(m);   // row_bcast:15
+        m = dpp_fmax<0x143, 0xc>(m);   // row_bcast:31
+        const double wm = read_lane_f64(m, 63);
+        const unsigned long long eq = __ballot(v == wm);
+        if (lane == 0) {
+            rv[par * 16 + wid] = wm;
+            ri[par * 16 + wid] = eq ? vp * B + wlo + (int)__ffsll((long long)eq) - 1 : 0x7fffffff;
+        }
+        __syncthreads();
+        double a = -INFINITY;
+        int ai = 0x7fffffff;
+        if (lane < nw) { a = rv[par * 16 + lane]; ai = ri[par * 16 + lane]; }
+        const double pm = row16_prefix_max(a);
+        G = read_lane_f64(pm, 15);
+        const unsigned long long eq2 = __ballot(a == G) & 0xffffull;
+        kg = __builtin_amdgcn_readlane(ai, eq2 ? (int)__ffsll((long long)eq2) - 1 : 0);
+        par ^= 1;
+    };
+    block_argmax(myv);
+
+    int cur = 0;
+    for (int t = 1; t < T; ++t) {
+        double lp = 0.0;
+        if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
+
+        const double *vi0 = valI + (cur * 2 + 0) * PADB + b2c;
+        const double *vi1 = valI + (cur * 2 + 1) * PADB + b2c;
+        const double *ve0 = valE + (cur * 2 + 0) * 2 * H;
+        const double *ve1 = valE + (cur * 2 + 1) * 2 * H;
+        const double *lt_e1 = lt_e0 + (size_t)2 * NC * W;
+        // two independent compare chains (voiced sources, unvoiced sources), each in state-index
+        // order: low-edge rows, interior rows, high-edge rows; merged in index order at the end.
+        // code: [0,64) low-edge source e, [64,192) interior offset d, [192,..) high-edge source.
+        // edge sources: table offset of (source e, this lane) = lane base + e*(W-1); pairs out of
+        // reach are redirected to the -inf sentinel (LDS copy) or predicated (global table).
+        // The opaque copy of b' keeps these cheap per-step integer ops from being hoisted out of
+        // the time loop into ~50 live registers.
+        int bl = b2c;
+        asm volatile("" : "+v"(bl));
+        const int ebase_lo = bl + H;                              // source b = e,      class e
+        const int ebase_hi = (bl - B + 2 * H) + (H + 1) * W;      // source b = B-H+e,  class H+1+e
+        const int reach_lo = act ? bl - H : 0x7fffffff;           // low source e in reach  <=> e >= reach_lo
+        const int reach_hi = act ? bl - (B - 2 * H) : -1;         // high source e in reach <=> e <= reach_hi
+
+        // interior-row sources: two independent compare chains (voiced / unvoiced sources)
+        double best = -INFINITY, best1 = -INFINITY;
+        int code = 0, code1 = 0;
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 4)
+        best = vi0[H] + lti0[H]; best1 = vi1[H] + lti1[H];
+#else
+#pragma unroll
+        for (int d = 0; d < W; ++d) {
+            const double cand = vi0[d] + lti0[W - 1 - d];
+            if (cand > best) code = d;
+            best = fmax(best, cand);
+            const double cand1 = vi1[d] + lti1[W - 1 - d];
+            if (cand1 > best1) code1 = d;
+            best1 = fmax(best1, cand1);
+        }
+#endif
+        int src = b2c + code - H, src1 = b2c + code1 - H;    // source bins of the two chains
+#if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
+        if (wave_low) {     // low-edge sources precede the interior ones in state order: they win ties
+            double eb = -INFINITY, eb1 = -INFINITY;
+            int ec = 0, ec1 = 0;
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                const bool ok = e >= reach_lo;
+                const int off = (LT_LDS && !ok) ? kSentinel : ebase_lo + e * (W - 1);
+                const double cand = (LT_LDS || ok) ? ve0[e] + lt_e0[off] : -INFINITY;
+                if (cand > eb) ec = e;
+                eb = fmax(eb, cand);
+                const double cand1 = (LT_LDS || ok) ? ve1[e] + lt_e1[off] : -INFINITY;
+                if (cand1 > eb1) ec1 = e;
+                eb1 = fmax(eb1, cand1);
+            }
+            if (eb >= best) { best = eb; src = ec; }
+            if (eb1 >= best1) { best1 = eb1; src1 = ec1; }
+        }
+        if (wave_high) {    // high-edge sources follow the interior ones: they lose ties
+            double eb = -INFINITY, eb1 = -INFINITY;
+            int ec = 0, ec1 = 0;
+#pragma unroll
+            for (int e = 0; e < H; ++e) {
+                const bool ok = e <= reach_hi;
+                const int off = (LT_LDS && !ok) ? kSentinel : ebase_hi + e * (W - 1);
+                const double cand = (LT_LDS || ok) ? ve0[H + e] + lt_e0[off] : -INFINITY;
+                if (cand > eb) ec = e;
+                eb = fmax(eb, cand);
+                const double cand1 = (LT_LDS || ok) ? ve1[H + e] + lt_e1[off] : -INFINITY;
+                if (cand1 > eb1) ec1 = e;
+                eb1 = fmax(eb1, cand1);
+            }
+            if (eb > best) { best = eb; src = B - H + ec; }
+            if (eb1 > best1) { best1 = eb1; src1 = B - H + ec1; }
+        }
+#endif
+        int bi = src;
+        if (best1 > best) { best = best1; bi = B + src1; }
+        // the one out-of-band candidate that can win: the previous column's arg-max
+        {
+            const int bg = kg >= B ? kg - B : kg;
+            const int dist = bg > b2c ? bg - b2c : b2c - bg;
+            if (dist > H) {
+                const double cand = G + p.log_tiny;
+                if (cand > best || (cand == best && kg < bi)) { best = cand; bi = kg; }
+            }
+        }
+        myv = -INFINITY;
+        if (act) {
+            myv = lp + best;
+            store_value(cur ^ 1, myv);
+            ring[((t - 1) % C) * S + j] = (uint16_t)bi;
+            ptr[(int64_t)t * S + j] = (uint16_t)bi;
+        }
+        block_argmax(myv);
+        cur ^= 1;
+        if (t % C == 0 || t == T - 1) {
+            const int cc = (t - 1) / C;
+            if (act) {
+                int s = j;
+                for (int tt = t; tt > cc * C; --tt) s = ring[((tt - 1) % C) * S + s];
+                cmap[(int64_t)cc * S + j] = (uint16_t)s;
+            }
+            __syncthreads();
+        }
+    }
+
+    if (tid == 0) {
+        int s = kg;
+        for (int cc = nch - 1; cc >= 0; --cc) { bnd[cc] = s; s = cmap[(int64_t)cc * S + s]; }
+        states[0] = s;
+    }
+    __threadfence();
+    __syncthreads();
+    for (int cc = tid; cc < nch; cc += nthr) {
+        const int te = min((cc + 1) * C, T - 1);
+        int s = bnd[cc];
+        states[te] = s;
+        for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
+    }
+}
+
+template <int H>
+static size_t viterbi_band_lds(const PassParams &p, bool lt_lds) {
+    const int B = p.n_bins, S = 2 * B;
+    const int PADB = (B + 2 * H + 64 + 7) & ~7;
+    size_t b = (((size_t)(4 * PADB + 8 * H + 32) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16) * 16;
+    if (lt_lds) b += (size_t)4 * p.n_cls * (2 * H + 1) * 8;
+    return b;
+}
+
+// ------------------------------------------------------------------------------------------
 // Kernel 5a: f0 / voiced decode (pitch.py: f0 = freqs[state % B], voiced = state < B).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void decode_kernel(PassParams p, DevTables tb) {
@@ -731,7 +1001,13 @@ static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
 }
 
 hipError_t viterbi_configure() {
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<25, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<50, false>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -747,9 +1023,29 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_frames == 0) return;
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_frames), dim3(64), 0, s, p, t);
 }
-hipError_t launch_viterbi(const PassParams &p, const DevTables &t, hipStream_t s) {
+hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {
     if (p.n_clips == 0) return hipSuccess;
     const int S = 2 * p.n_bins;
+    const int BP = (p.n_bins + 63) & ~63;
+    if (p.n_cls == p.width && 2 * BP <= 1024 && p.n_bins >= 4 * p.half_width + 128) {
+        // band-specialised kernels for the two hop/sr ratios the reference uses (44.1k and 22.05k at hop 512)
+        if (p.half_width == 25 && viterbi_band_lds<25>(p, true) <= 160 * 1024) {
+            BandLT<25> blt;
+            for (int q = 0; q < 4; ++q)
+                std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 25) * p.width, sizeof(blt.v[q]));
+            hipLaunchKernelGGL((viterbi_band_kernel<25, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
+                               viterbi_band_lds<25>(p, true), s, p, t, blt);
+            return hipGetLastError();
+        }
+        if (p.half_width == 50 && viterbi_band_lds<50>(p, false) <= 160 * 1024) {
+            BandLT<50> blt;
+            for (int q = 0; q < 4; ++q)
+                std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 50) * p.width, sizeof(blt.v[q]));
+            hipLaunchKernelGGL((viterbi_band_kernel<50, false>), dim3((unsigned)p.n_clips), dim3(2 * BP),
+                               viterbi_band_lds<50>(p, false), s, p, t, blt);
+            return hipGetLastError();
+        }
+    }
     const int nthr = (S + 63) & ~63;
     const bool with_lt = viterbi_lds_bytes(p, true) <= 160 * 1024;
     const size_t lds = viterbi_lds_bytes(p, with_lt);
