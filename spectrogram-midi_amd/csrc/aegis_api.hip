@@ -183,6 +183,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRT(upload_table(h, t.thresholds, &h->dt.thresholds));
     CRT(upload_table(h, t.beta_probs, &h->dt.beta_probs));
     CRT(upload_table(h, t.beta_cumsum, &h->dt.beta_cumsum));
+    CRT(upload_table(h, t.beta_suffix, &h->dt.beta_suffix));
     CRT(upload_table(h, t.boltz_fact, &h->dt.boltz_fact));
     CRT(upload_table(h, t.boltz_exp, &h->dt.boltz_exp));
     CRT(upload_table(h, t.log_trans_band, &h->dt.lt_band));
@@ -461,6 +462,7 @@ int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int6
     else if (n == "thresholds") setd(t.thresholds);
     else if (n == "beta_probs") setd(t.beta_probs);
     else if (n == "beta_cumsum") setd(t.beta_cumsum);
+    else if (n == "beta_suffix") setd(t.beta_suffix);
     else if (n == "boltz_fact") setd(t.boltz_fact);
     else if (n == "boltz_exp") setd(t.boltz_exp);
     else if (n == "log_trans_band") setd(t.log_trans_band);

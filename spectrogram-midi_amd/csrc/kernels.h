@@ -16,6 +16,7 @@ struct DevTables {
     const double *thresholds;  // [101]
     const double *beta_probs;  // [100]
     const double *beta_cumsum; // [101]
+    const double *beta_suffix; // [101]
     const double *boltz_fact;  // [n]
     const double *boltz_exp;   // [n]
     const double *lt_band;     // [4][n_cls][width]

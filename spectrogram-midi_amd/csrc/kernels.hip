@@ -13,6 +13,7 @@
 // NumPy rounds; fused operations are written as fma() where they are wanted.
 #include "kernels.h"
 
+#include <algorithm>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -39,15 +40,16 @@ __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_doub
 
 // ------------------------------------------------------------------------------------------
 // 2048-point complex FFT, float64, Stockham autosort in LDS: five radix-4 passes and one
-// radix-2 pass, 256 threads.  Forward transform (e^{-2 pi i jk/N}); input and result in `a`,
-// `b` is the second buffer.  Caller synchronises before the call; returns synchronised.
+// radix-2 pass by NT cooperating threads.  Forward transform (e^{-2 pi i jk/N}); input and
+// result in `a`, `b` is the second buffer.  Callers synchronise before the call; every pass
+// ends with a workgroup barrier, so all threads of the workgroup must make the same calls.
 // ------------------------------------------------------------------------------------------
-template <int NS>
+template <int NS, int NT>
 __device__ __forceinline__ void fft_pass_r4(const double2 *__restrict__ in, double2 *__restrict__ out,
                                             const double2 *__restrict__ tw, int tid) {
 #pragma unroll
-    for (int jj = 0; jj < 2; ++jj) {
-        const int j = tid + jj * 256;
+    for (int jj = 0; jj < 512 / NT; ++jj) {
+        const int j = tid + jj * NT;
         const int k = j & (NS - 1);
         double2 v0 = in[j], v1 = in[j + 512], v2 = in[j + 1024], v3 = in[j + 1536];
         if (NS > 1) {
@@ -67,11 +69,12 @@ __device__ __forceinline__ void fft_pass_r4(const double2 *__restrict__ in, doub
     }
 }
 
+template <int NT>
 __device__ __forceinline__ void fft_pass_r2_last(const double2 *__restrict__ in, double2 *__restrict__ out,
                                                  const double2 *__restrict__ tw, int tid) {
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const int j = tid + jj * 256;   // 0..1023, Ns = 1024 -> k = j, j0 = j
+    for (int jj = 0; jj < 1024 / NT; ++jj) {
+        const int j = tid + jj * NT;   // 0..1023, Ns = 1024 -> k = j, j0 = j
         const double2 v0 = in[j];
         const double2 v1 = cmul(in[j + 1024], tw[j]);
         out[j] = cadd(v0, v1);
@@ -79,66 +82,79 @@ __device__ __forceinline__ void fft_pass_r2_last(const double2 *__restrict__ in,
     }
 }
 
+template <int NT>
 __device__ __forceinline__ void fft2048(double2 *a, double2 *b, const double2 *__restrict__ tw, int tid) {
-    fft_pass_r4<1>(a, b, tw, tid);   __syncthreads();
-    fft_pass_r4<4>(b, a, tw, tid);   __syncthreads();
-    fft_pass_r4<16>(a, b, tw, tid);  __syncthreads();
-    fft_pass_r4<64>(b, a, tw, tid);  __syncthreads();
-    fft_pass_r4<256>(a, b, tw, tid); __syncthreads();
-    fft_pass_r2_last(b, a, tw, tid); __syncthreads();
+    fft_pass_r4<1, NT>(a, b, tw, tid);   __syncthreads();
+    fft_pass_r4<4, NT>(b, a, tw, tid);   __syncthreads();
+    fft_pass_r4<16, NT>(a, b, tw, tid);  __syncthreads();
+    fft_pass_r4<64, NT>(b, a, tw, tid);  __syncthreads();
+    fft_pass_r4<256, NT>(a, b, tw, tid); __syncthreads();
+    fft_pass_r2_last<NT>(b, a, tw, tid); __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 1: one frame per 256-thread workgroup.
-//   * loads the centred frame (zero padded at the clip edges) with coalesced reads
+// Kernel 1: two frames per 512-thread workgroup (one per 256-thread half).
+//   * loads the centred frames (zero padded at the clip edges) with coalesced reads
 //   * RMS in NumPy's float32 pairwise-summation order (bit-exact with np.mean)
-//   * packed FFT of (frame, reversed half frame) -> spectrum product -> inverse FFT
-//     = the autocorrelation acf[tau] = sum_{j=1..1024} x[j] x[j+tau], tau <= max_period
-//   * Hann-windowed FFT -> |X|^2 (rounded through complex64 like librosa.stft) -> mel
+//   * one packed forward FFT per frame: Z = FFT(x + i*b), b = reversed first half of the frame.
+//       A = FFT(x), B = FFT(b) are separated from Z by symmetry;
+//       P = A*B is the spectrum of pyin's autocorrelation;
+//       the Hann-windowed spectrum librosa.stft needs is XW[k] = A[k]/2 - (A[k-1] + A[k+1])/4
+//       (periodic Hann = 1/2 - 1/4 e^{+i..} - 1/4 e^{-i..}), so the mel path costs no FFT.
+//   * ONE inverse FFT for both frames: Q = P0 + i*P1 (Hermitian extensions) -> acf0 + i*acf1
+//   * |XW|^2 rounded through complex64 like librosa.stft -> Slaney mel -> clip max
+// 1.5 FFTs per frame instead of 3.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void frame_fft_kernel(PassParams p, DevTables tb) {
-    __shared__ double2 bufA[2048];
-    __shared__ double2 bufB[2048];
-    __shared__ float xs[2048];
-    __shared__ float pw[1032];
-    __shared__ float red[128];
-    __shared__ float blk[16];
-    __shared__ unsigned smax;
+__global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables tb) {
+    extern __shared__ __align__(16) unsigned char fsm[];
+    double2 *bufs = reinterpret_cast<double2 *>(fsm);            // [2 halves][2][2048]
+    float *xs_all = reinterpret_cast<float *>(bufs + 4 * 2048);  // [2][2048]
+    float *pw_all = xs_all + 2 * 2048;                           // [2][1032]
+    float *red_all = pw_all + 2 * 1032;                          // [2][128]
+    float *blk_all = red_all + 2 * 128;                          // [2][16]
+    unsigned *smax_all = reinterpret_cast<unsigned *>(blk_all + 2 * 16);   // [2]
 
-    const int tid = threadIdx.x;
-    const int64_t f = blockIdx.x;
-    const int c = find_clip(p.frame_off, p.n_clips, f);
-    const int64_t t = f - p.frame_off[c];
-    const int64_t base = p.sample_off[c];
-    const int64_t n = p.sample_off[c + 1] - base;
-    const int64_t start = t * p.hop - 1024;
+    const int tid = threadIdx.x, hh = tid >> 8, lt = tid & 255;
+    double2 *bufA = bufs + hh * 4096, *bufB = bufA + 2048;
+    float *xs = xs_all + hh * 2048, *pw = pw_all + hh * 1032, *red = red_all + hh * 128, *blk = blk_all + hh * 16;
 
+    const int64_t f = (int64_t)blockIdx.x * 2 + hh;
+    const bool live = f < p.n_frames;
+    int c = 0;
+    int64_t base = 0, n = 0, start = 0;
+    if (live) {
+        c = find_clip(p.frame_off, p.n_clips, f);
+        base = p.sample_off[c];
+        n = p.sample_off[c + 1] - base;
+        start = (f - p.frame_off[c]) * p.hop - 1024;
+    }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        const int i = tid + r * 256;
+        const int i = lt + r * 256;
         const int64_t idx = start + i;
-        xs[i] = (idx >= 0 && idx < n) ? p.pcm[base + idx] : 0.0f;
+        xs[i] = (live && idx >= 0 && idx < n) ? p.pcm[base + idx] : 0.0f;
     }
-    if (tid == 0) smax = 0u;
+    if (lt == 0) smax_all[hh] = 0u;
     __syncthreads();
 
     // ---- feature.rms: np.mean(np.square(x), axis=-2) then sqrt, float32 ----------------------
-    if ((p.stages & 0x8u) && p.out_rms != nullptr) {
-        if (tid < 128) {
-            const int bb = tid >> 3, a = tid & 7;
+    const bool want_rms = (p.stages & 0x8u) && p.out_rms != nullptr;
+    if (want_rms) {
+        if (lt < 128) {
+            const int bb = lt >> 3, a = lt & 7;
             const float *xb = xs + bb * 128 + a;
             float r = xb[0] * xb[0];
 #pragma unroll
             for (int i = 1; i < 16; ++i) { const float v = xb[8 * i]; r = r + v * v; }
-            red[tid] = r;
+            red[lt] = r;
         }
         __syncthreads();
-        if (tid < 16) {
-            const float *r = red + tid * 8;
-            blk[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        if (lt < 16) {
+            const float *r = red + lt * 8;
+            blk[lt] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
         }
         __syncthreads();
-        if (tid == 0) {
+        if (lt == 0 && live) {
             float b0 = (blk[0] + blk[1]) + (blk[2] + blk[3]);
             float b1 = (blk[4] + blk[5]) + (blk[6] + blk[7]);
             float b2 = (blk[8] + blk[9]) + (blk[10] + blk[11]);
@@ -147,60 +163,87 @@ __global__ __launch_bounds__(256) void frame_fft_kernel(PassParams p, DevTables 
             p.out_rms[f] = sqrtf(total / 2048.0f);
         }
     }
+    if (!(p.stages & 0x7u)) return;
 
-    // ---- pYIN autocorrelation via one packed forward FFT and one inverse FFT -----------------
-    if (p.stages & 0x4u) {
+    // ---- packed forward FFT of (frame, reversed first half) ---------------------------------
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = tid + r * 256;
-            bufA[i] = make_double2((double)xs[i], i < 1024 ? (double)xs[1024 - i] : 0.0);
-        }
-        __syncthreads();
-        fft2048(bufA, bufB, tb.twiddle, tid);
-        // Z = FFT(x + i b):  A = (Z[k] + conj Z[N-k]) / 2,  B = (Z[k] - conj Z[N-k]) / 2i,
-        // P = A*B.  bufB receives conj(Q) where Q is the Hermitian extension of P, so that
-        // Re(FFT(conj Q)) / N is the inverse transform.
-        for (int k = tid; k <= 1024; k += 256) {
+    for (int r = 0; r < 8; ++r) {
+        const int i = lt + r * 256;
+        bufA[i] = make_double2((double)xs[i], i < 1024 ? (double)xs[1024 - i] : 0.0);
+    }
+    __syncthreads();
+    fft2048<256>(bufA, bufB, tb.twiddle, lt);
+
+    // A[k] -> bufB[k] (k <= 1024); P[k] = A[k]*B[k] kept in registers
+    double2 P[5];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+        const int k = lt + r * 256;
+        P[r] = make_double2(0.0, 0.0);
+        if (k <= 1024) {
             const double2 zk = bufA[k], zn = bufA[(2048 - k) & 2047];
             const double2 A = make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
             const double2 Bv = make_double2((zk.y + zn.y) * 0.5, (zn.x - zk.x) * 0.5);
-            const double2 P = cmul(A, Bv);
-            bufB[k] = make_double2(P.x, -P.y);
-            if (k > 0 && k < 1024) bufB[2048 - k] = P;
+            P[r] = cmul(A, Bv);
+            bufB[k] = A;
         }
-        __syncthreads();
-        fft2048(bufB, bufA, tb.twiddle, tid);
-        double *acf = p.acf + f * (int64_t)p.lag_stride;
-        for (int tau = tid; tau <= p.max_period; tau += 256) acf[tau] = bufB[1024 + tau].x * (1.0 / 2048.0);
-        __syncthreads();
     }
-
-    // ---- melspectrogram: Hann window (float64) -> FFT -> complex64 -> |.|^2 -> Slaney mel -----
-    if (p.stages & 0x3u) {
+    __syncthreads();
+    // windowed power spectrum from A (bufB); P -> bufA[k]
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int i = tid + r * 256;
-            bufA[i] = make_double2(tb.hann[i] * (double)xs[i], 0.0);
+    for (int r = 0; r < 5; ++r) {
+        const int k = lt + r * 256;
+        if (k <= 1024) {
+            if (p.stages & 0x3u) {
+                const double2 a0 = bufB[k];
+                double2 am = bufB[k == 0 ? 1 : k - 1], ap = bufB[k == 1024 ? 1023 : k + 1];
+                if (k == 0) am.y = -am.y;          // A[-1] = conj(A[1])
+                if (k == 1024) ap.y = -ap.y;       // A[1025] = conj(A[1023])
+                const float re = (float)(0.5 * a0.x - 0.25 * (am.x + ap.x));
+                const float im = (float)(0.5 * a0.y - 0.25 * (am.y + ap.y));
+                const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
+                pw[k] = mag * mag;
+            }
+            bufA[k] = P[r];
         }
-        __syncthreads();
-        fft2048(bufA, bufB, tb.twiddle, tid);
-        for (int k = tid; k <= 1024; k += 256) {
-            const float re = (float)bufA[k].x, im = (float)bufA[k].y;
-            const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
-            pw[k] = mag * mag;
-        }
-        __syncthreads();
-        if (tid < p.n_mels) {
-            const int s0 = tb.mel_start[tid], len = tb.mel_len[tid];
-            const float *w = tb.mel_w + tb.mel_off[tid];
+    }
+    __syncthreads();
+
+    // ---- mel projection (each half: its own frame) -------------------------------------------
+    if (p.stages & 0x3u) {
+        if (lt < p.n_mels && live) {
+            const int s0 = tb.mel_start[lt], len = tb.mel_len[lt];
+            const float *w = tb.mel_w + tb.mel_off[lt];
             float acc = 0.0f;
             for (int i = 0; i < len; ++i) acc = fmaf(w[i], pw[s0 + i], acc);
-            p.melpow[f * p.n_mels + tid] = acc;
-            atomicMax(&smax, __float_as_uint(acc));
+            p.melpow[f * p.n_mels + lt] = acc;
+            atomicMax(&smax_all[hh], __float_as_uint(acc));
+        }
+    }
+    // ---- one inverse FFT for both frames -------------------------------------------------------
+    if (p.stages & 0x4u) {
+        // conj(Q), Q = Hermitian extension of P0 + i*P1, built by all 512 threads into bufs[0].B
+        double2 *q = bufs + 2048, *q2 = bufs + 3 * 2048;
+        const double2 *P0 = bufs, *P1 = bufs + 4096;
+        for (int k = tid; k <= 1024; k += 512) {
+            const double2 u = P0[k], v = P1[k];
+            q[k] = make_double2(u.x - v.y, -u.y - v.x);                       // conj(P0) - i conj(P1)
+            if (k > 0 && k < 1024) q[2048 - k] = make_double2(u.x + v.y, u.y - v.x);   // P0 - i P1
         }
         __syncthreads();
-        if (tid == 0) atomicMax(&p.clipmax[c], smax);
+        fft2048<512>(q, q2, tb.twiddle, tid);
+        // FFT(conj Q) = N * conj(acf0 + i acf1)
+        if (live) {
+            double *acf = p.acf + f * (int64_t)p.lag_stride;
+            for (int tau = lt; tau <= p.max_period; tau += 256) {
+                const double2 z = q[1024 + tau];
+                acf[tau] = (hh == 0 ? z.x : -z.y) * (1.0 / 2048.0);
+            }
+        }
+    } else {
+        __syncthreads();
     }
+    if ((p.stages & 0x3u) && lt == 0 && live) atomicMax(&p.clipmax[c], smax_all[hh]);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -208,6 +251,19 @@ __global__ __launch_bounds__(256) void frame_fft_kernel(PassParams p, DevTables 
 // reference (np.cumsum in float32 for the energy, in float64 for the CMND denominator), so
 // the lanes walk their own frame serially and stay bit-exact with NumPy.
 // ------------------------------------------------------------------------------------------
+// 8 consecutive samples x[idx..idx+7] with zero fill outside [0, n); one 128-byte line per lane
+// is consumed by four such calls, so the wave's loads of a line stay adjacent in time.
+__device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, int64_t idx, bool vec_ok, float (&v)[8]) {
+    if (vec_ok && idx >= 0 && idx + 7 < n) {
+        const float4 a = *reinterpret_cast<const float4 *>(x + idx);
+        const float4 b = *reinterpret_cast<const float4 *>(x + idx + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const int64_t q = idx + i; v[i] = (q >= 0 && q < n) ? x[q] : 0.0f; }
+    }
+}
+
 __global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
     const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
     if (f >= p.n_frames) return;
@@ -217,36 +273,55 @@ __global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
     const int64_t n = p.sample_off[c + 1] - base;
     const int64_t start = t * p.hop - 1024;
     const float *__restrict__ x = p.pcm + base;
+    // float4 loads need 16-byte aligned addresses: clip base and hop multiples of 4 samples
+    const bool vec_ok = ((base & 3) == 0) && ((p.hop & 3) == 0);
 
-    // e_hi = cumsum(x^2)[k] for k < 1024
+    // e_hi = cumsum(x^2)[k] for k < 1024 (float32, strictly sequential like np.cumsum)
     float e_hi = 0.0f;
-    for (int k = 0; k < 1024; ++k) {
-        const int64_t idx = start + k;
-        const float v = (idx >= 0 && idx < n) ? x[idx] : 0.0f;
-        const float sq = v * v;
-        e_hi = (k == 0) ? sq : e_hi + sq;
+    float v[8], w[8];
+    for (int k = 0; k < 1024; k += 8) {
+        load8(x, n, start + k, vec_ok, v);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float sq = v[i] * v[i];
+            e_hi = (k + i == 0) ? sq : e_hi + sq;
+        }
     }
     const double *__restrict__ acf = p.acf + f * (int64_t)p.lag_stride;
     double *__restrict__ yin = p.yin + f * (int64_t)p.yin_stride;
     float e_lo = 0.0f, en0 = 0.0f;
     double cs = 0.0;
-    for (int tau = 0; tau <= p.max_period; ++tau) {
-        int64_t idx = start + 1024 + tau;
-        float v = (idx >= 0 && idx < n) ? x[idx] : 0.0f;
-        e_hi = e_hi + v * v;
-        idx = start + tau;
-        v = (idx >= 0 && idx < n) ? x[idx] : 0.0f;
-        const float sq = v * v;
-        e_lo = (tau == 0) ? sq : e_lo + sq;
-        float en = e_hi - e_lo;
-        if (fabsf(en) < 1e-6f) en = 0.0f;
-        if (tau == 0) en0 = en;
-        double a = acf[tau];
-        if (fabs(a) < 1e-6) a = 0.0;
-        const float esum = en0 + en;
-        const double d = (double)esum - 2.0 * a;
-        if (tau >= 1) cs = (tau == 1) ? d : cs + d;
-        if (tau >= p.min_period) yin[tau - p.min_period] = d / (cs / (double)tau + DBL_MIN);
+    for (int tau0 = 0; tau0 <= p.max_period; tau0 += 8) {
+        load8(x, n, start + 1024 + tau0, vec_ok, v);
+        load8(x, n, start + tau0, vec_ok, w);
+        double a8[8];
+        if (tau0 + 7 < p.lag_stride) {     // rows are padded to a multiple of 8 lags
+#pragma unroll
+            for (int i = 0; i < 8; i += 2) {
+                const double2 a2 = *reinterpret_cast<const double2 *>(acf + tau0 + i);
+                a8[i] = a2.x; a8[i + 1] = a2.y;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a8[i] = tau0 + i <= p.max_period ? acf[tau0 + i] : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int tau = tau0 + i;
+            if (tau > p.max_period) break;
+            e_hi = e_hi + v[i] * v[i];
+            const float sq = w[i] * w[i];
+            e_lo = (tau == 0) ? sq : e_lo + sq;
+            float en = e_hi - e_lo;
+            if (fabsf(en) < 1e-6f) en = 0.0f;
+            if (tau == 0) en0 = en;
+            double a = a8[i];
+            if (fabs(a) < 1e-6) a = 0.0;
+            const float esum = en0 + en;
+            const double d = (double)esum - 2.0 * a;
+            if (tau >= 1) cs = (tau == 1) ? d : cs + d;
+            if (tau >= p.min_period) yin[tau - p.min_period] = d / (cs / (double)tau + DBL_MIN);
+        }
     }
 }
 
@@ -266,21 +341,38 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     return v;
 }
 
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_imin(int v) {
+    return min(v, __builtin_amdgcn_update_dpp(v, v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ int wave_min_i32(int v) {   // uniform result
+    v = dpp_imin<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_imin<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_imin<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_imin<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_imin<0x142, 0xa>(v);   // row_bcast:15
+    v = dpp_imin<0x143, 0xc>(v);   // row_bcast:31
+    return __builtin_amdgcn_readlane(v, 63);
+}
+
 __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb) {
-    __shared__ double y[1024];
-    __shared__ double th[kKMax];
-    __shared__ double tp[kKMax];
-    __shared__ double row[512];
-    __shared__ int16_t ti[kKMax];
-    __shared__ int16_t tbin[kKMax];
-    __shared__ uint8_t twin[kKMax];
+    // dynamic LDS: y[max(n_lags, n_bins)] (reused as the output row), th[KM], tp[KM], ti[KM], tbin[KM], twin[KM]
+    extern __shared__ __align__(16) unsigned char osm[];
+    const int nl = p.n_lags, B = p.n_bins;
+    const int KM = nl / 2 + 2;
+    const int YN = (max(nl, B) + 1) & ~1;
+    double *y = reinterpret_cast<double *>(osm);
+    double *row = y;                       // written only after the last read of y
+    double *th = y + YN;
+    double *tp = th + KM;
+    int16_t *ti = reinterpret_cast<int16_t *>(tp + KM);
+    int16_t *tbin = ti + KM;
+    uint8_t *twin = reinterpret_cast<uint8_t *>(tbin + KM);
 
     const int lane = threadIdx.x;
     const int64_t f = blockIdx.x;
-    const int nl = p.n_lags, B = p.n_bins;
     const double *__restrict__ yr = p.yin + f * (int64_t)p.yin_stride;
     for (int i = lane; i < nl; i += 64) y[i] = yr[i];
-    for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
     __syncthreads();
 
     // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
@@ -308,8 +400,8 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     __syncthreads();
 
     double vp = 0.0;
+    const int rounds = (K + 63) >> 6;
     if (K > 0) {
-        const int rounds = (K + 63) >> 6;
         int jk[kMaxRounds];
         double acc[kMaxRounds];
         int jmin = 101;
@@ -332,32 +424,42 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
                 }
             }
         }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) jmin = min(jmin, __shfl_xor(jmin, o));
+        jmin = wave_min_i32(jmin);
 
+        // probs[k] = sum_j [h_k < thr_{j+1}] * boltzmann.pmf(pos_k(j); 2, n_j) * beta_probs[j].
+        // The set of troughs below threshold j only changes where j passes some trough's first
+        // threshold, so j runs over those change points and each stretch [j, next) contributes
+        // prior * (beta_suffix[j] - beta_suffix[next]).  (librosa evaluates this sum with a BLAS
+        // dot product whose order is unspecified; agreement is to rounding, ~1e-16.)
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        for (int j = jmin; j < 100; ++j) {
+        int j = jmin;
+        while (j < 100) {
             unsigned long long M[kMaxRounds];
-            int nj = 0;
+            int nj = 0, nxt = 100;
 #pragma unroll
             for (int q = 0; q < kMaxRounds; ++q) {
                 M[q] = 0ull;
-                if (q < rounds) { M[q] = __ballot(jk[q] <= j); nj += __popcll(M[q]); }
+                if (q < rounds) {
+                    M[q] = __ballot(jk[q] <= j);
+                    nj += __popcll(M[q]);
+                    if (jk[q] > j) nxt = min(nxt, jk[q]);
+                }
             }
+            nxt = wave_min_i32(nxt);
             const double fact = tb.boltz_fact[nj];
-            const double bj = tb.beta_probs[j];
+            const double wgt = tb.beta_suffix[j] - tb.beta_suffix[nxt];   // small-end sums: no cancellation
             int before = 0;
 #pragma unroll
             for (int q = 0; q < kMaxRounds; ++q) {
                 if (q < rounds) {
                     if (jk[q] <= j) {
                         const int pos = before + __popcll(M[q] & lt_mask);
-                        const double prior = fact * tb.boltz_exp[pos];
-                        acc[q] = fma(prior, bj, acc[q]);
+                        acc[q] = fma(fact * tb.boltz_exp[pos], wgt, acc[q]);
                     }
                     before += __popcll(M[q]);
                 }
             }
+            j = nxt;
         }
 
         // global minimum trough (first index on ties) gets the no-trough mass
@@ -408,7 +510,11 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
                 tbin[k] = (int16_t)bin;
             }
         }
-        __syncthreads();
+    }
+    __syncthreads();                 // last read of y is behind us: the buffer becomes the output row
+    for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
+    __syncthreads();
+    if (K > 0) {
         // observation_probs[bin, t] = probs: on duplicate bins the largest lag wins; bins are
         // non-increasing in lag, so a trough loses exactly when the next trough with
         // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
@@ -993,6 +1099,8 @@ void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, 
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
+constexpr size_t kFrameLds = (size_t)4 * 2048 * 16 + (2 * 2048 + 2 * 1032 + 2 * 128 + 2 * 16) * 4 + 16;
+
 static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
     const int S = 2 * p.n_bins, SP = (S + 63) & ~63;
     size_t b = ((size_t)(2 * SP + 32) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16 * 16;
@@ -1001,7 +1109,10 @@ static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
 }
 
 hipError_t viterbi_configure() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(frame_fft_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<25, true>),
@@ -1013,7 +1124,7 @@ hipError_t viterbi_configure() {
 
 void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_frames == 0 || !(p.stages & 0xFu)) return;
-    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)p.n_frames), dim3(256), 0, s, p, t);
+    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((p.n_frames + 1) / 2)), dim3(512), kFrameLds, s, p, t);
 }
 void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
     if (p.n_frames == 0) return;
@@ -1021,7 +1132,9 @@ void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_frames == 0) return;
-    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_frames), dim3(64), 0, s, p, t);
+    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1;
+    const size_t lds = (size_t)(YN + 2 * KM) * 8 + (size_t)KM * 5 + 16;
+    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_frames), dim3(64), lds, s, p, t);
 }
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {
     if (p.n_clips == 0) return hipSuccess;

@@ -133,6 +133,8 @@ std::string Tables::build(int sr_, int hop_, int n_fft_, int n_mels_, double fmi
         for (int i = 0; i < kNThresholds; ++i) beta_probs[i] = cdf[i + 1] - cdf[i];
         beta_cumsum.resize(kNThresholds + 1);
         for (int n = 0; n <= kNThresholds; ++n) beta_cumsum[n] = np_pairwise_sum(beta_probs.data(), n);
+        beta_suffix.assign(kNThresholds + 1, 0.0);
+        for (int n = kNThresholds - 1; n >= 0; --n) beta_suffix[n] = beta_suffix[n + 1] + beta_probs[n];
         // scipy.stats.boltzmann._pmf: fact = (1-exp(-l))/(1-exp(-l*N)); fact*exp(-l*k)
         const int nb = n_lags / 2 + 2;
         boltz_fact.assign(nb + 1, 0.0); boltz_exp.assign(nb + 1, 0.0);

@@ -36,6 +36,7 @@ struct Tables {
     std::vector<double> thresholds;    // [101]
     std::vector<double> beta_probs;    // [100]
     std::vector<double> beta_cumsum;   // [101]  np.sum(beta_probs[:n])
+    std::vector<double> beta_suffix;   // [101]  sum(beta_probs[n:]) accumulated from the small end
     std::vector<double> boltz_fact;    // [n]    (1-e^-2)/(1-e^-2N)
     std::vector<double> boltz_exp;     // [n]    e^-2k
     std::vector<double> log_trans_band; // [4][n_cls][width]  (v*2+v') major
