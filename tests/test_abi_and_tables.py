@@ -1,0 +1,104 @@
+"""CPU checks of the C-ABI library: it loads, exports every symbol include/aegis_hip.h declares,
+builds its host tables without touching a GPU (device=-1), those tables match the NumPy/SciPy
+constructions of the oracle, and analyze calls fail loudly without a device."""
+import os
+import re
+
+import numpy as np
+import pytest
+import scipy.stats
+
+from oracle import dsp, pyin as opyin
+from spectrogram_midi_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def host_handle():
+    h = _lib.Handle(device=-1)
+    yield h
+    h.close()
+
+
+def test_header_symbols_are_exported():
+    hdr = open(os.path.join(ROOT, "include", "aegis_hip.h")).read()
+    declared = set(re.findall(r"\b(aegis_[a-z_]+)\s*\(", hdr))
+    lib = _lib.load()
+    assert declared and declared == set(_lib.EXPORTS)
+    for sym in declared:
+        assert hasattr(lib, sym), sym
+    assert lib.aegis_abi_version() == 1
+
+
+def test_geometry(host_handle):
+    h = host_handle
+    assert [h.param(k) for k in ("min_period", "max_period", "n_lags", "n_pitch_bins", "transition_width")] == \
+        [42, 536, 495, 441, 51]
+    assert h.frames_for(0) == 1 and h.frames_for(184014) == 360 and h.frames_for(7938000) == 15504
+
+
+def test_tables_match_numpy_scipy(host_handle):
+    h = host_handle
+    p = opyin.PyinParams()
+    np.testing.assert_array_equal(h.table("hann"), dsp.hann_periodic(2048))
+    np.testing.assert_array_equal(h.table("mel_dense").reshape(128, 1025), dsp.mel_filterbank(44100, 2048))
+    np.testing.assert_array_equal(h.table("thresholds"), p.thresholds)
+    np.testing.assert_allclose(h.table("beta_probs"), p.beta_probs, rtol=1e-12)
+    np.testing.assert_allclose(h.table("beta_cumsum"), [np.sum(p.beta_probs[:n]) for n in range(101)], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(h.table("beta_suffix"), [np.sum(p.beta_probs[n:]) for n in range(101)], rtol=1e-12, atol=1e-300)
+    np.testing.assert_allclose(h.table("freqs"), p.freqs, rtol=4e-16)
+    fact, ex = h.table("boltz_fact"), h.table("boltz_exp")
+    for N in (1, 2, 5, 31, 248):
+        np.testing.assert_allclose(fact[N] * ex[:N], scipy.stats.boltzmann.pmf(np.arange(N), 2.0, N), rtol=1e-15)
+    tw = h.table("twiddle").reshape(-1, 2)
+    np.testing.assert_allclose(tw[:, 0] + 1j * tw[:, 1], np.exp(-2j * np.pi * np.arange(2048) / 2048), atol=1e-15)
+
+
+def test_banded_transition_table(host_handle):
+    """The kernels use a 51-class band-compressed log-transition table: edge rows exact, interior
+    rows share one representative normalisation (<= 1 ulp from librosa's per-row sums)."""
+    p = opyin.PyinParams()
+    LT = np.log(opyin.transition_matrix(p) + opyin.TINY)
+    B, H, W = 441, 25, 51
+    band = host_handle.table("log_trans_band").reshape(4, 51, 51)
+    cls = lambda b: b if b < H else (b - (B - 1 - 2 * H) if b > B - 1 - H else H)
+    worst = 0.0
+    for v in range(2):
+        for v2 in range(2):
+            for b in range(B):
+                js = np.arange(max(0, b - H), min(B, b + H + 1))
+                ref = LT[v * B + b, v2 * B + js]
+                got = band[v * 2 + v2, cls(b), js - b + H]
+                worst = max(worst, np.abs(ref - got).max())
+                if b < H or b > B - 1 - H:
+                    np.testing.assert_array_equal(got, ref)
+    assert worst < 4e-15
+    # everything outside the band is log(tiny)
+    assert LT[0, 200] == np.log(opyin.TINY)
+
+
+def test_other_configuration_and_rejections():
+    h = _lib.Handle(sample_rate=22050, device=-1)
+    assert (h.param("min_period"), h.param("max_period"), h.param("transition_width")) == (21, 268, 101)
+    np.testing.assert_array_equal(h.table("mel_dense").reshape(128, 1025), dsp.mel_filterbank(22050, 2048))
+    h.close()
+    with pytest.raises(_lib.AegisError):
+        _lib.Handle(n_fft=1024, device=-1)
+    with pytest.raises(_lib.AegisError):
+        _lib.Handle(fmin=500.0, fmax=100.0, device=-1)
+
+
+def test_no_cpu_fallback(host_handle):
+    with pytest.raises(_lib.AegisError) as e:
+        host_handle.analyze_batch([np.zeros(1000, np.float32)])
+    assert e.value.code == _lib.ERR_DEVICE
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, "spectrogram-midi_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn

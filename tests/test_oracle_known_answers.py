@@ -1,0 +1,112 @@
+"""Pins the CPU oracle (oracle/) with analytic known answers -- the anchors SURVEY.md 8c lists in
+lieu of librosa golden vectors (the reference holds none; librosa is absent).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import dsp, engine as oengine, pyin as opyin
+
+SR = 44100
+
+
+def sine(freq, seconds, amp=0.5):
+    t = np.arange(int(SR * seconds)) / SR
+    return (amp * np.sin(2 * np.pi * freq * t)).astype(np.float32)
+
+
+def test_note_frequencies():
+    assert dsp.note_to_hz("E2") == 82.4068892282175
+    assert dsp.note_to_hz("C6") == 1046.5022612023945
+    assert dsp.hz_to_midi(440.0) == 69.0
+
+
+def test_pyin_geometry():
+    p = opyin.PyinParams()
+    assert (p.min_period, p.max_period, p.n_lags) == (42, 536, 495)
+    assert p.n_pitch_bins == 441 and p.transition_width == 51 and p.max_semitones_per_frame == 5
+    assert 12 * 10 * np.log2(p.fmax / p.fmin) == 440.0
+    p2 = opyin.PyinParams(sr=22050)
+    assert (p2.min_period, p2.max_period, p2.n_lags, p2.transition_width) == (21, 268, 248, 101)
+    T = opyin.transition_matrix(p)
+    assert T.shape == (882, 882) and np.allclose(T.sum(axis=1), 1.0)
+    assert np.count_nonzero(T[300]) == 102           # 51-wide band x 2 voicing blocks
+
+
+def test_frame_count_and_padding():
+    for n in (0, 1, 511, 512, 513, 44100):
+        y = np.zeros(n, np.float32)
+        assert len(dsp.rms(y)) == 1 + n // 512
+        assert dsp.melspectrogram(y).shape == (128, 1 + n // 512)
+
+
+def test_pure_sine_tracks_a2():
+    f0, voiced, prob = opyin.pyin(sine(110.0, 2.0))
+    inner = slice(4, -4)
+    p = opyin.PyinParams()
+    assert voiced[inner].all()
+    assert np.all(f0[inner] == p.freqs[50])          # fmin * 2^(50/120) = 110 Hz bin
+    assert abs(p.freqs[50] - 110.0) < 1e-9
+    assert np.all(prob[inner] > 0.99)
+
+
+def test_silence_is_unvoiced():
+    f0, voiced, prob = opyin.pyin(np.zeros(SR, np.float32))
+    assert not voiced.any() and np.isnan(f0).all() and np.all(prob == 0)
+
+
+def test_rms_of_sine():
+    r = dsp.rms(sine(441.0, 1.0, amp=0.5))            # 441 Hz: 100-sample period
+    assert np.allclose(r[4:-4], 0.5 / np.sqrt(2), rtol=2e-3)
+
+
+def test_mel_filterbank_slaney_area():
+    fb = dsp.mel_filterbank(SR, 2048)
+    assert fb.shape == (128, 1025) and fb.dtype == np.float32 and (fb >= 0).all()
+    df = SR / 2048
+    area = fb.sum(axis=1) * df                         # slaney norm: unit area per band
+    assert np.allclose(area[5:], 1.0, rtol=0.15)
+    assert np.all(np.diff(np.argmax(fb, axis=1)) >= 0)
+
+
+def test_stft_parseval():
+    rng = np.random.default_rng(0)
+    y = rng.normal(0, 0.1, 8192).astype(np.float32)
+    D = dsp.stft(y)
+    win = dsp.hann_periodic(2048)
+    frames = dsp.frame_centered(y, 2048, 512).astype(np.float64) * win[:, None]
+    full = np.abs(D.astype(np.complex128)) ** 2
+    energy = (full[0] + full[-1] + 2 * full[1:-1].sum(axis=0)) / 2048
+    assert np.allclose(energy, (frames ** 2).sum(axis=0), rtol=1e-5)
+
+
+def test_db_range():
+    S = dsp.melspectrogram(sine(220.0, 1.0))
+    db = dsp.power_to_db(S)
+    assert db.max() == 0.0 and db.min() >= -80.0 and db.dtype == np.float32
+    a = dsp.amplitude_to_db(np.array([1e-9, 0.5, 1.0], np.float32))
+    assert a[2] == 0.0 and a[0] == -80.0 and abs(a[1] + 6.0206) < 1e-3
+
+
+def test_c_and_numpy_viterbi_agree():
+    y = np.concatenate([sine(110, 0.6), np.zeros(4000, np.float32), sine(330, 0.5, 0.2)])
+    a = opyin.pyin(y, use_c=True)
+    b = opyin.pyin(y, use_c=False)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(np.nan_to_num(a[0]), np.nan_to_num(b[0]))
+
+
+def test_turbo_chunking_rule():
+    # aegis_engine.py:192-204 with 8 cores on a 10 s clip: 862 ceil-frames -> 107 per core
+    spans = oengine.turbo_chunks(441000, SR, 512, 8)
+    assert len(spans) == 8 and spans[0] == (0, 107 * 512) and spans[-1] == (7 * 107 * 512, 441000)
+    assert oengine.turbo_chunks(100, SR, 512, 8) == [(0, 100)]
+
+
+def test_tick_rule_and_smf_header():
+    from oracle import smf
+    ev = [{"note": 45, "start": 10, "end": 40, "confidence": 0.9, "velocity": 100, "track": "main",
+           "rms_energy": -3.0, "technique": None, "slope": 0.0}]
+    blob = smf.write_smf(ev, SR, 512)
+    typ, tpb, tracks = smf.parse_smf(blob)
+    assert (typ, tpb, len(tracks)) == (1, 480, 2)
+    on_tick = int(10 * (512 / SR) * 960)
+    assert tracks[0][0][1] == 0xC0 and tracks[0][1] == (on_tick, 0x90, bytes([45, 100]))
+    assert tracks[0][-1][1] == 0xFF and tracks[1][-1][1] == 0xFF      # end_of_track appended
