@@ -111,6 +111,14 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
  * Returns the element count (or a negative code); copies min(count, cap) elements. */
 int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int64_t cap);
 
+/* Replaces one of the float64 prior tables with caller-supplied values (same length as the
+ * built-in one): "beta_probs" [100] (beta_cumsum / beta_suffix are re-derived), "boltz_fact",
+ * "boltz_exp", "freqs".  librosa builds these with scipy.stats / numpy at every call
+ * (core/pitch.py::pyin); the Python binding passes the same arrays so that the observation
+ * probabilities are bit-identical to the reference on that host.  C callers may keep the
+ * built-in closed forms (within 1e-14 relative). */
+int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64_t count);
+
 /* Scalar parameters derived at create time.  name in {"min_period","max_period",
  * "n_lags","n_pitch_bins","transition_width","n_trans_classes","max_frames_per_pass",
  * "lag_stride","yin_stride","obs_stride","last_frames"}. */

@@ -114,7 +114,11 @@ def observation(yin, shifts, p):
         with np.errstate(all="ignore"):
             prior = scipy.stats.boltzmann.pmf(pos, p.boltzmann, n_tr)
         prior[~below] = 0
-        probs = prior.dot(p.beta_probs)
+        # librosa: trough_prior.dot(beta_probs) -- a BLAS product whose summation order is
+        # unspecified.  The restatement fixes it: products added in ascending threshold order.
+        probs = np.zeros(len(idx))
+        for j in range(p.n_thresholds):
+            probs = probs + prior[:, j] * p.beta_probs[j]
         g = np.argmin(h)
         n_below_min = np.count_nonzero(~below[g, :])
         probs[g] += p.no_trough_prob * np.sum(p.beta_probs[:n_below_min])

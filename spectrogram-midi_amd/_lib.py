@@ -31,7 +31,7 @@ class Outputs(C.Structure):
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
-           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns")
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table")
 
 _lib = None
 
@@ -63,6 +63,8 @@ def load():
     lib.aegis_analyze_batch_device.restype = C.c_int
     lib.aegis_rake_patterns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_void_p]
     lib.aegis_rake_patterns.restype = C.c_int
+    lib.aegis_set_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+    lib.aegis_set_table.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_get_table.restype = C.c_int64
     lib.aegis_get_param.argtypes = [C.c_void_p, C.c_char_p]
@@ -86,7 +88,7 @@ class Handle:
     host tables only (no GPU touched)."""
 
     def __init__(self, sample_rate=44100, hop_length=512, n_fft=2048, n_mels=128, fmin=0.0, fmax=0.0,
-                 device=0, max_frames_per_pass=0):
+                 device=0, max_frames_per_pass=0, scipy_tables=True):
         self.lib = load()
         cfg = Config(sample_rate, hop_length, n_fft, n_mels, fmin, fmax, device, 0, max_frames_per_pass)
         h = C.c_void_p()
@@ -95,6 +97,29 @@ class Handle:
             raise AegisError(rc, self.lib.aegis_last_error(None).decode())
         self._h = h
         self.sr, self.hop, self.n_fft, self.n_mels, self.device = sample_rate, hop_length, n_fft, n_mels, device
+        if scipy_tables:
+            self._load_scipy_tables()
+
+    def _load_scipy_tables(self):
+        """The pYIN prior tables exactly as librosa builds them per call (core/pitch.py::pyin:
+        scipy.stats.beta.cdf over linspace thresholds, scipy.stats.boltzmann.pmf, the pitch-bin
+        frequencies), so the kernels work from the same float64 values as the reference."""
+        import scipy.stats
+        thresholds = np.linspace(0, 1, 101)
+        self.set_table("beta_probs", np.diff(scipy.stats.beta.cdf(thresholds, 2, 18)))
+        n = len(self.table("boltz_fact"))
+        lam, idx = 2.0, np.arange(n)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            fact = (1 - np.exp(-lam)) / (1 - np.exp(-lam * idx))      # scipy.stats.boltzmann._pmf
+        fact[0] = 0.0
+        self.set_table("boltz_fact", fact)
+        self.set_table("boltz_exp", np.exp(-lam * idx))
+        fmin, nb = self.table("freqs")[0], self.param("n_pitch_bins")
+        self.set_table("freqs", fmin * 2 ** (np.arange(nb) / 120))
+
+    def set_table(self, name, values):
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        self._check(self.lib.aegis_set_table(self._h, name.encode(), v.ctypes.data, len(v)))
 
     def close(self):
         if getattr(self, "_h", None):

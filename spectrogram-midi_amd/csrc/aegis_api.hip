@@ -432,6 +432,47 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
     return AEGIS_OK;
 }
 
+int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64_t count) {
+    if (!h || !name || !data) return AEGIS_ERR_INVALID;
+    Tables &t = h->tab;
+    const std::string n(name);
+    struct Slot { std::vector<double> *host; const double *dev; };
+    auto slot = [&](const std::string &nm) -> Slot {
+        if (nm == "beta_probs") return {&t.beta_probs, h->dt.beta_probs};
+        if (nm == "beta_cumsum") return {&t.beta_cumsum, h->dt.beta_cumsum};
+        if (nm == "beta_suffix") return {&t.beta_suffix, h->dt.beta_suffix};
+        if (nm == "boltz_fact") return {&t.boltz_fact, h->dt.boltz_fact};
+        if (nm == "boltz_exp") return {&t.boltz_exp, h->dt.boltz_exp};
+        if (nm == "freqs") return {&t.freqs, h->dt.freqs};
+        return {nullptr, nullptr};
+    };
+    auto push = [&](const std::string &nm) -> int {
+        Slot s = slot(nm);
+        if (h->device < 0) return AEGIS_OK;
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipMemcpy(const_cast<double *>(s.dev), s.host->data(), s.host->size() * 8, hipMemcpyHostToDevice));
+        return AEGIS_OK;
+    };
+    Slot s = slot(n);
+    if (!s.host || n == "beta_cumsum" || n == "beta_suffix") { h->err = "unknown or derived table: " + n; return AEGIS_ERR_INVALID; }
+    if (count != (int64_t)s.host->size()) {
+        h->err = "table " + n + " needs " + std::to_string(s.host->size()) + " entries";
+        return AEGIS_ERR_INVALID;
+    }
+    std::copy(data, data + count, s.host->begin());
+    int rc = push(n);
+    if (rc != AEGIS_OK) return rc;
+    if (n == "beta_probs") {
+        for (int k = 0; k <= kNThresholds; ++k) t.beta_cumsum[k] = np_pairwise_sum(t.beta_probs.data(), k);
+        t.beta_suffix.assign(kNThresholds + 1, 0.0);
+        for (int k = kNThresholds - 1; k >= 0; --k) t.beta_suffix[k] = t.beta_suffix[k + 1] + t.beta_probs[k];
+        if ((rc = push("beta_cumsum")) != AEGIS_OK) return rc;
+        if ((rc = push("beta_suffix")) != AEGIS_OK) return rc;
+    }
+    return AEGIS_OK;
+}
+
 int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (!h || !name) return AEGIS_ERR_INVALID;
     const Tables &t = h->tab;

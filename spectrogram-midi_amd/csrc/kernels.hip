@@ -368,11 +368,13 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     int16_t *ti = reinterpret_cast<int16_t *>(tp + KM);
     int16_t *tbin = ti + KM;
     uint8_t *twin = reinterpret_cast<uint8_t *>(tbin + KM);
+    __shared__ double beta_s[104];
 
     const int lane = threadIdx.x;
     const int64_t f = blockIdx.x;
     const double *__restrict__ yr = p.yin + f * (int64_t)p.yin_stride;
     for (int i = lane; i < nl; i += 64) y[i] = yr[i];
+    for (int i = lane; i < 100; i += 64) beta_s[i] = tb.beta_probs[i];
     __syncthreads();
 
     // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
@@ -426,11 +428,11 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         }
         jmin = wave_min_i32(jmin);
 
-        // probs[k] = sum_j [h_k < thr_{j+1}] * boltzmann.pmf(pos_k(j); 2, n_j) * beta_probs[j].
+        // probs[k] = sum_j [h_k < thr_{j+1}] * boltzmann.pmf(pos_k(j); 2, n_j) * beta_probs[j],
+        // products added in ascending j (the order the oracle fixes for librosa's BLAS dot).
         // The set of troughs below threshold j only changes where j passes some trough's first
-        // threshold, so j runs over those change points and each stretch [j, next) contributes
-        // prior * (beta_suffix[j] - beta_suffix[next]).  (librosa evaluates this sum with a BLAS
-        // dot product whose order is unspecified; agreement is to rounding, ~1e-16.)
+        // threshold, so the prior is rebuilt at those change points only; inside a stretch every
+        // j still contributes its own rounded product, which keeps the sum bit-identical.
         const unsigned long long lt_mask = (1ull << lane) - 1ull;
         int j = jmin;
         while (j < 100) {
@@ -447,17 +449,21 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
             }
             nxt = wave_min_i32(nxt);
             const double fact = tb.boltz_fact[nj];
-            const double wgt = tb.beta_suffix[j] - tb.beta_suffix[nxt];   // small-end sums: no cancellation
+            double prior[kMaxRounds];
             int before = 0;
 #pragma unroll
             for (int q = 0; q < kMaxRounds; ++q) {
+                prior[q] = 0.0;
                 if (q < rounds) {
-                    if (jk[q] <= j) {
-                        const int pos = before + __popcll(M[q] & lt_mask);
-                        acc[q] = fma(fact * tb.boltz_exp[pos], wgt, acc[q]);
-                    }
+                    if (jk[q] <= j) prior[q] = fact * tb.boltz_exp[before + __popcll(M[q] & lt_mask)];
                     before += __popcll(M[q]);
                 }
+            }
+            for (int jj = j; jj < nxt; ++jj) {
+                const double bj = beta_s[jj];
+#pragma unroll
+                for (int q = 0; q < kMaxRounds; ++q)
+                    if (q < rounds) acc[q] = acc[q] + prior[q] * bj;
             }
             j = nxt;
         }

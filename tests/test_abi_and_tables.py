@@ -16,8 +16,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.fixture(scope="module")
 def host_handle():
-    h = _lib.Handle(device=-1)
+    h = _lib.Handle(device=-1, scipy_tables=False)      # the library's built-in closed-form tables
     yield h
+    h.close()
+
+
+def test_python_binding_feeds_scipy_tables():
+    """The binding replaces the prior tables with the arrays librosa itself would build, bit for bit."""
+    h = _lib.Handle(device=-1)
+    p = opyin.PyinParams()
+    np.testing.assert_array_equal(h.table("beta_probs"), p.beta_probs)
+    np.testing.assert_array_equal(h.table("beta_cumsum"), [np.sum(p.beta_probs[:n]) for n in range(101)])
+    np.testing.assert_array_equal(h.table("freqs"), p.freqs)
+    fact, ex = h.table("boltz_fact"), h.table("boltz_exp")
+    for N in (1, 2, 3, 17, 100, 248):
+        np.testing.assert_array_equal(fact[N] * ex[:N], scipy.stats.boltzmann.pmf(np.arange(N), 2.0, N))
+    with pytest.raises(_lib.AegisError):
+        h.set_table("beta_probs", np.zeros(7))
+    with pytest.raises(_lib.AegisError):
+        h.set_table("hann", np.zeros(2048))
     h.close()
 
 

@@ -1,0 +1,170 @@
+"""End-to-end parity of the AegisEngine surface on the GPU against the oracle, plus the
+size-independent properties used at BASELINE.json sizes.  Calls go through the C ABI."""
+import io
+import os
+
+import numpy as np
+import pytest
+
+from oracle import engine as oengine, pyin as opyin, dsp as odsp, rake as orake
+from spectrogram_midi_amd import _lib, audio_io, signals
+from spectrogram_midi_amd.engine import AegisEngine
+from spectrogram_midi_amd.worker import _pyin_worker
+
+pytestmark = pytest.mark.gpu
+EV_KEYS = ("note", "start", "end", "velocity", "track", "technique")
+
+
+def assert_raw_equal(raw, ref, tag=""):
+    np.testing.assert_array_equal(raw["voiced_flag"], ref["voiced_flag"], err_msg=tag)
+    np.testing.assert_array_equal(raw["rake_mask"], ref["rake_mask"], err_msg=tag)
+    np.testing.assert_array_equal(raw["rms"], ref["rms"], err_msg=tag)
+    np.testing.assert_allclose(raw["f0"], ref["f0"], rtol=1e-13, err_msg=tag)
+    np.testing.assert_allclose(raw["voiced_probs"], ref["voiced_probs"], rtol=1e-9, atol=1e-12, err_msg=tag)
+
+
+def assert_events_equal(ev, ref, tag=""):
+    assert [[e[k] for k in EV_KEYS] for e in ev] == [[e[k] for k in EV_KEYS] for e in ref], tag
+    np.testing.assert_allclose([e["confidence"] for e in ev], [e["confidence"] for e in ref], rtol=1e-9, atol=1e-12)
+    np.testing.assert_allclose([e["slope"] for e in ev], [e["slope"] for e in ref], rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal([e["rms_energy"] for e in ev], [e["rms_energy"] for e in ref])
+
+
+@pytest.fixture(scope="module")
+def eng():
+    e = AegisEngine()
+    yield e
+    e.close()
+
+
+def test_fixture_track_events_and_midi(eng, tmp_path):
+    """BASELINE configs[0]: the reference's own synthetic guitar fixture through the file API."""
+    y = signals.guitar_test_track()
+    wav = str(tmp_path / "synthetic_guitar_test.wav")
+    audio_io.write_wav(wav, y, 44100)
+    y16 = audio_io.read_wav(wav, 44100)
+    raw = eng.audio_to_midi(wav, None, rake_sensitivity=0.6)
+    ref = oengine.audio_to_midi(y16)
+    assert_raw_equal(raw, ref)
+    np.testing.assert_array_equal(raw["y"], y16)
+    buf = io.BytesIO()
+    ev = eng.extract_events(raw, buf)
+    ev_ref, blob_ref = oengine.extract_events(ref, want_smf=True)
+    assert_events_equal(ev, ev_ref)
+    assert buf.getvalue() == blob_ref
+    yl, S_dB = eng.load_audio(wav)
+    np.testing.assert_allclose(S_dB, ref["S_dB"], atol=2e-3)
+    assert S_dB.shape == (128, 360) and S_dB.max() == 0.0 and S_dB.min() >= -80.0
+    part = eng.audio_to_midi(wav, None, start_time=1.0, end_time=3.0)
+    assert_raw_equal(part, oengine.audio_to_midi(audio_io.read_wav(wav, 44100, 1.0, 2.0)))
+
+
+def test_sweep_and_empty(eng):
+    y = signals.sine_sweep(10.0)
+    assert_raw_equal(eng.analyze_array(y), oengine.audio_to_midi(y), "sweep")
+    assert eng.analyze_array(np.zeros(0, np.float32)) is None
+    out = eng.analyze_arrays([np.zeros(0, np.float32), y[:30000]])
+    assert out[0] is None and len(out[1]["f0"]) == 59
+    with pytest.raises(ValueError):
+        eng.analyze_array(np.array([0.0, np.nan, 0.1], np.float32))
+
+
+def test_turbo_mode_matches_reference_chunking(eng):
+    y = signals.guitar_clip(12.0, seed=3)
+    for cores in (8, 3):
+        eng.turbo_cores = cores
+        f0, vf, vp = eng._parallel_pitch_tracking(y)
+        rf0, rvf, rvp = oengine.parallel_pitch_tracking(y, num_cores=cores)
+        assert len(f0) == len(rf0) > 1 + len(y) // 512            # one extra frame per chunk
+        np.testing.assert_array_equal(vf, rvf)
+        np.testing.assert_allclose(np.nan_to_num(f0), np.nan_to_num(rf0), rtol=1e-13)
+    raw = eng.analyze_array(y, turbo_mode=True)
+    ref = oengine.audio_to_midi(y, turbo_mode=True, num_cores=3)
+    assert_raw_equal(raw, ref, "turbo")
+    assert_events_equal(eng.extract_events(raw, None), oengine.extract_events(ref))
+    short = y[: 4 * 44100]                                   # < 5 s: single-pass bypass (aegis_engine.py:189)
+    a = eng._parallel_pitch_tracking(short)
+    b = opyin.pyin(short)
+    np.testing.assert_array_equal(a[1], b[1])
+    eng.turbo_cores = None
+
+
+def test_pyin_worker(eng):
+    chunk = signals.guitar_clip(3.0, seed=4)
+    f0, vf, vp = _pyin_worker((chunk, 44100, 512))
+    r = opyin.pyin(chunk)
+    np.testing.assert_array_equal(vf, r[1])
+    np.testing.assert_allclose(np.nan_to_num(f0), np.nan_to_num(r[0]), rtol=1e-13)
+    assert np.isnan(f0[~vf]).all()
+
+
+def test_detect_rake_patterns_against_reference_goldens(eng):
+    """aegis_rake_patterns (GPU) vs masks produced by the reference's vision.py itself."""
+    G = np.load(os.path.join(os.path.dirname(__file__), "golden", "rake_golden.npz"))
+    for i, (n_mels, F, sr, hop, ratio) in enumerate(G["cases"]):
+        h = _lib.Handle(sample_rate=int(sr), hop_length=int(hop))
+        got = h.rake_patterns(G[f"S_{i}"], float(ratio))
+        np.testing.assert_array_equal(got, G[f"mask_{i}"], err_msg=f"case {i}")
+        h.close()
+    np.testing.assert_array_equal(eng.detect_rake_patterns(G["S_0"]), orake.detect_rake_patterns(G["S_0"], 512, 44100, 0.6))
+
+
+@pytest.mark.parametrize("sr,hop", [(22050, 512), (44100, 256), (48000, 512), (44100, 1024)])
+def test_other_rates_and_hops(sr, hop):
+    """v2 engine rate (aegis_engine_financial.py:36) uses the H=50 band kernel; the others take
+    the generic Viterbi kernel (transition widths 31, 51@48k, 101)."""
+    y = signals.guitar_clip(4.0, sr=sr, seed=9)
+    h = _lib.Handle(sample_rate=sr, hop_length=hop)
+    r = h.analyze_batch([y])[0]
+    f0, vf, vp = opyin.pyin(y, sr=sr, hop_length=hop)
+    np.testing.assert_array_equal(r["voiced_flag"], vf)
+    np.testing.assert_allclose(np.nan_to_num(r["f0"]), np.nan_to_num(f0), rtol=1e-13)
+    np.testing.assert_array_equal(r["rms"], odsp.rms(y, hop_length=hop))
+    S_dB = odsp.power_to_db(odsp.melspectrogram(y, sr=sr, hop_length=hop))
+    np.testing.assert_allclose(r["S_dB"], S_dB, atol=2e-3)
+    np.testing.assert_array_equal(r["rake_mask"], orake.detect_rake_patterns(S_dB, hop, sr, 0.6))
+    h.close()
+
+
+def test_three_minute_clip_midi_matches_oracle(eng):
+    """BASELINE configs[1]: one 180 s 44.1 kHz clip, full path, MIDI diffed against the CPU oracle."""
+    y = signals.guitar_clip(180.0, seed=1)
+    raw = eng.analyze_array(y)
+    ref = oengine.audio_to_midi(y)
+    assert len(raw["f0"]) == 15504
+    assert_raw_equal(raw, ref, "180s")
+    ev, ev_ref = eng.extract_events(raw, None), oengine.extract_events(ref)
+    assert len(ev) > 50
+    assert_events_equal(ev, ev_ref, "180s")
+
+
+def test_batch_properties_at_scale():
+    """Size-independent properties on 64 clips of up to 30 s (configs[2] shape): results do not
+    depend on batch composition, order, pass splitting or repetition."""
+    rng = np.random.default_rng(0)
+    clips = [signals.guitar_clip(float(rng.uniform(2.0, 30.0)), seed=100 + i) if i % 8 else
+             signals.polyphonic_clip(float(rng.uniform(2.0, 30.0)), seed=100 + i) for i in range(16)]
+    clips = clips * 4                                         # 64 clips, ragged
+    h = _lib.Handle()
+    a = h.analyze_batch(clips)
+    b = h.analyze_batch(clips)
+    perm = rng.permutation(len(clips))
+    c = h.analyze_batch([clips[i] for i in perm])
+    small = _lib.Handle(max_frames_per_pass=4000)             # forces many passes
+    d = small.analyze_batch(clips)
+    for i in range(len(clips)):
+        for k in a[i]:
+            np.testing.assert_array_equal(a[i][k], b[i][k], err_msg=f"rerun {i}/{k}")
+            np.testing.assert_array_equal(a[i][k], d[i][k], err_msg=f"passes {i}/{k}")
+            np.testing.assert_array_equal(a[i][k], a[i % 16][k], err_msg=f"duplicate {i}/{k}")
+    for pos, i in enumerate(perm):
+        for k in a[i]:
+            np.testing.assert_array_equal(c[pos][k], a[i][k], err_msg=f"perm {i}/{k}")
+    for i in (0, 5, 8):                                        # and spot-check against the oracle
+        ref = oengine.audio_to_midi(clips[i])
+        np.testing.assert_array_equal(a[i]["voiced_flag"], ref["voiced_flag"])
+        np.testing.assert_array_equal(a[i]["rake_mask"], ref["rake_mask"])
+        np.testing.assert_allclose(np.nan_to_num(a[i]["f0"]), ref["f0"], rtol=1e-13)
+    with pytest.raises(_lib.AegisError):
+        small.analyze_batch([np.zeros(4001 * 512, np.float32)])   # one clip larger than a pass
+    h.close(); small.close()

@@ -75,6 +75,9 @@ def test_observation(run):
         # the unvoiced observation is compared in the linear domain
         np.testing.assert_allclose(np.exp(lu), obs[441], rtol=1e-9, atol=1e-15, err_msg=k)
         np.testing.assert_allclose(run["res"][i]["voiced_prob"], run["ora"][k]["vp"], rtol=1e-10, atol=1e-12)
+        # same scipy tables + same summation order: the prior masses are bit-identical, which is
+        # what keeps log(1 - voiced_prob) from decaying into rounding noise (parity notes)
+        np.testing.assert_array_equal(run["res"][i]["voiced_prob"], run["ora"][k]["vp"], err_msg=k)
 
 
 def test_pitch_track_exact(run):
