@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstring>
 #include <map>
 #include <numeric>
@@ -27,7 +29,7 @@ struct DevBuf {
 };
 
 struct PassMeta {   // host copies kept alive until the stream has consumed them
-    std::vector<int64_t> sample_off, frame_off, chunk_off;
+    std::vector<int64_t> sample_off, frame_off, chunk_off, sel_off;
     std::vector<int32_t> order;
 };
 
@@ -38,12 +40,14 @@ struct aegis_handle {
     DevTables dt{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
+    std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
     int64_t max_frames_per_pass = 0;
     mutable std::string err;
     std::vector<void *> table_allocs;
     // workspace (grow-only)
     DevBuf acf, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
-    DevBuf sample_off, frame_off, order;
+    DevBuf sample_off, frame_off, order, sel_off, vstate;
     DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb;
     int32_t lag_stride = 0, yin_stride = 0, obs_stride = 0;
     std::vector<PassMeta> metas;
@@ -172,6 +176,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
 #define CRTHIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e__); return fail(AEGIS_ERR_DEVICE); } } while (0)
     CRTHIP(hipSetDevice(c.device));
     CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CRTHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CRTHIP(viterbi_configure());
 
     const Tables &t = h->tab;
@@ -204,13 +209,16 @@ void aegis_destroy(aegis_handle *h) {
     if (h->device < 0) { delete h; return; }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (void *p : h->table_allocs) (void)hipFree(p);
     for (DevBuf *b : {&h->acf, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
                       &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
-                      &h->order, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
+                      &h->order, &h->sel_off, &h->vstate, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb})
         free_buf(*b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
+    if (h->stream2) (void)hipStreamDestroy(h->stream2);
     delete h;
 }
 
@@ -339,16 +347,61 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
         p.rake_ratio = rake_sensitivity;
         p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
 
-        begin_event(h, "frame_fft", s); launch_frame_fft(p, h->dt, s); end_event(h, s);
-        if (py) {
-            begin_event(h, "yin_seq", s); launch_yin_seq(p, h->dt, s); end_event(h, s);
-            begin_event(h, "pyin_obs", s); launch_pyin_obs(p, h->dt, s); end_event(h, s);
-            begin_event(h, "viterbi", s);
-            hipError_t ve = launch_viterbi(p, h->dt, t.log_trans_band.data(), s);
-            end_event(h, s);
-            if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+        // ---- time-chunked pipeline --------------------------------------------------------------
+        // The Viterbi recurrence is sequential in time and occupies one compute unit per clip; the
+        // frame-stage kernels are wide.  Long clips are therefore cut into time chunks of kTimeChunk
+        // Viterbi steps: chunk k's frame stage runs on `s` while chunk k-1's Viterbi runs on the
+        // handle's second stream, carrying its column of values exactly (vstate) across launches.
+        constexpr int64_t kTimeChunk = 2048;      // multiple of kViterbiChunk
+        int64_t maxF = 0;
+        for (int i = 0; i < nc; ++i) maxF = std::max(maxF, frames[first + i]);
+        const int nk = (py && maxF > kTimeChunk + kTimeChunk / 2) ? (int)((maxF - 1 + kTimeChunk - 1) / kTimeChunk) : 1;
+        auto chunk_lo = [&](int k) { return k == 0 ? (int64_t)0 : 1 + k * kTimeChunk; };
+        auto chunk_hi = [&](int k) { return k == nk - 1 ? maxF : 1 + (k + 1) * kTimeChunk; };
+        m.sel_off.assign((size_t)nk * (nc + 1), 0);
+        for (int k = 0; k < nk; ++k)
+            for (int i = 0; i < nc; ++i) {
+                const int64_t cnt = std::max<int64_t>(0, std::min(frames[first + i], chunk_hi(k)) - chunk_lo(k));
+                m.sel_off[(size_t)k * (nc + 1) + i + 1] = m.sel_off[(size_t)k * (nc + 1) + i] + cnt;
+            }
+        if ((rc = ensure(h, h->sel_off, (size_t)nk * (nc + 1) * 8)) != AEGIS_OK) return rc;
+        if (py && (rc = ensure(h, h->vstate, (size_t)nc * S * 8)) != AEGIS_OK) return rc;
+        HIPCHK(h, hipMemcpyAsync(h->sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, s));
+        p.vstate = static_cast<double *>(h->vstate.p);
+        hipStream_t sv = (nk > 1) ? h->stream2 : s;
+        while ((int)h->sync_events.size() < nk + 1) {
+            hipEvent_t e;
+            HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            h->sync_events.push_back(e);
         }
-        begin_event(h, "finalize", s); launch_finalize(p, h->dt, s); end_event(h, s);
+        for (int k = 0; k < nk; ++k) {
+            p.sel_off = static_cast<const int64_t *>(h->sel_off.p) + (size_t)k * (nc + 1);
+            p.t_begin = chunk_lo(k);
+            p.n_sel = m.sel_off[(size_t)k * (nc + 1) + nc];
+            p.vt_begin = chunk_lo(k);
+            p.vt_end = (k == nk - 1) ? INT64_MAX : chunk_hi(k);
+            begin_event(h, "frame_fft", s); launch_frame_fft(p, h->dt, s); end_event(h, s);
+            if (py) {
+                begin_event(h, "yin_seq", s); launch_yin_seq(p, h->dt, s); end_event(h, s);
+                begin_event(h, "pyin_obs", s); launch_pyin_obs(p, h->dt, s); end_event(h, s);
+                if (nk > 1) {
+                    HIPCHK(h, hipEventRecord(h->sync_events[k], s));
+                    HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[k], 0));
+                }
+                begin_event(h, "viterbi", sv);
+                hipError_t ve = launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
+                end_event(h, sv);
+                if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+            }
+        }
+        begin_event(h, "finalize", s); launch_finalize_mel(p, h->dt, s); end_event(h, s);
+        if (py) {
+            begin_event(h, "finalize", sv); launch_decode(p, h->dt, sv); end_event(h, sv);
+            if (nk > 1) {
+                HIPCHK(h, hipEventRecord(h->sync_events[nk], sv));
+                HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[nk], 0));
+            }
+        }
         HIPCHK(h, hipGetLastError());
         h->last_frames = fp;
         frame_base += fp;

@@ -40,6 +40,14 @@ struct PassParams {
     const int32_t *order;        // [n_clips] clip indices, longest first
     int32_t n_clips;
     int64_t n_frames;            // frames in this pass
+    // frame selection of this launch (time-chunked pipeline): clip c contributes its frames
+    // t_begin .. t_begin + (sel_off[c+1]-sel_off[c]) - 1; the whole pass is sel_off == frame_off, t_begin == 0
+    const int64_t *sel_off;      // [n_clips+1]
+    int64_t t_begin;
+    int64_t n_sel;
+    // Viterbi step range of this launch: t in [max(1, vt_begin), min(T, vt_end)); state carried in vstate
+    int64_t vt_begin, vt_end;
+    double *vstate;              // [n_clips][2*n_bins] column of values at the end of the previous launch
     // workspace (strides in elements)
     double *acf;   int32_t lag_stride;   // [F][lag_stride]   lags 0..max_period
     double *yin;   int32_t yin_stride;   // [F][yin_stride]   CMND for lags min..max
@@ -66,7 +74,8 @@ void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_yin_seq(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
-void launch_finalize(const PassParams &p, const DevTables &t, hipStream_t s);
+void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);
+void launch_finalize_mel(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, int min_frames, int max_frames,
                          uint8_t *raw, uint8_t *out, hipStream_t s);
 hipError_t viterbi_configure();   // raises the dynamic-LDS limit once

@@ -32,6 +32,13 @@ __device__ __forceinline__ int find_clip(const int64_t *__restrict__ frame_off, 
     return lo;
 }
 
+// selected-frame index of this launch -> (clip, frame within clip, frame within pass)
+__device__ __forceinline__ void map_frame(const PassParams &p, int64_t fs, int &c, int64_t &t, int64_t &f) {
+    c = find_clip(p.sel_off, p.n_clips, fs);
+    t = p.t_begin + (fs - p.sel_off[c]);
+    f = p.frame_off[c] + t;
+}
+
 __device__ __forceinline__ double2 cmul(double2 a, double2 b) {
     return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
@@ -118,15 +125,16 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     double2 *bufA = bufs + hh * 4096, *bufB = bufA + 2048;
     float *xs = xs_all + hh * 2048, *pw = pw_all + hh * 1032, *red = red_all + hh * 128, *blk = blk_all + hh * 16;
 
-    const int64_t f = (int64_t)blockIdx.x * 2 + hh;
-    const bool live = f < p.n_frames;
+    const int64_t fs = (int64_t)blockIdx.x * 2 + hh;
+    const bool live = fs < p.n_sel;
     int c = 0;
-    int64_t base = 0, n = 0, start = 0;
+    int64_t base = 0, n = 0, start = 0, f = 0;
     if (live) {
-        c = find_clip(p.frame_off, p.n_clips, f);
+        int64_t t;
+        map_frame(p, fs, c, t, f);
         base = p.sample_off[c];
         n = p.sample_off[c + 1] - base;
-        start = (f - p.frame_off[c]) * p.hop - 1024;
+        start = t * p.hop - 1024;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -265,10 +273,11 @@ __device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, in
 }
 
 __global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
-    const int64_t f = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (f >= p.n_frames) return;
-    const int c = find_clip(p.frame_off, p.n_clips, f);
-    const int64_t t = f - p.frame_off[c];
+    const int64_t fs = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    if (fs >= p.n_sel) return;
+    int c;
+    int64_t t, f;
+    map_frame(p, fs, c, t, f);
     const int64_t base = p.sample_off[c];
     const int64_t n = p.sample_off[c + 1] - base;
     const int64_t start = t * p.hop - 1024;
@@ -371,7 +380,12 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     __shared__ double beta_s[104];
 
     const int lane = threadIdx.x;
-    const int64_t f = blockIdx.x;
+    int64_t f;
+    {
+        int c;
+        int64_t t;
+        map_frame(p, (int64_t)blockIdx.x, c, t, f);
+    }
     const double *__restrict__ yr = p.yin + f * (int64_t)p.yin_stride;
     for (int i = lane; i < nl; i += 64) y[i] = yr[i];
     for (int i = lane; i < 100; i += 64) beta_s[i] = tb.beta_probs[i];
@@ -609,10 +623,18 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     const int dlo = max(0, H - b2);
     const int dhi = min(W - 1, B - 1 - b2 + H);
 
+    const int t_lo = (int)(p.vt_begin > 1 ? p.vt_begin : 1);
+    const int t_hi = (int)(p.vt_end < T ? p.vt_end : T);
+    if (p.vt_begin >= T && !(p.vt_begin == 0)) return;          // clip finished in an earlier launch
+    double *__restrict__ vst = p.vstate + (int64_t)c * S;
     double myv = -INFINITY;
     if (act) {
-        const double lp = v2 ? lunv[0] : lobs[b2];
-        myv = lp + p.log_pinit;
+        if (p.vt_begin == 0) {
+            const double lp = v2 ? lunv[0] : lobs[b2];
+            myv = lp + p.log_pinit;
+        } else {
+            myv = vst[j];
+        }
         val[j] = myv;
     }
     int par = 0;
@@ -638,7 +660,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     block_argmax(myv, act ? j : 0x7fffffff);
 
     double *cur = val, *nxt = val + SP;
-    for (int t = 1; t < T; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         double lp = 0.0;
         if (act) lp = v2 ? lunv[t] : lobs[(int64_t)t * os + b2];
         double best = -INFINITY;
@@ -679,6 +701,10 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
         }
     }
 
+    if (t_hi < T) {                       // more launches follow: hand the column over
+        if (act) vst[j] = myv;
+        return;
+    }
     // back-trace: serial over chunk maps, then parallel inside the chunks
     if (tid == 0) {
         int s = kg;
@@ -796,10 +822,18 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         else valI[(buf * 2 + vp) * PADB + b2c + H] = v;
     };
 
+    const int t_lo = (int)(p.vt_begin > 1 ? p.vt_begin : 1);
+    const int t_hi = (int)(p.vt_end < T ? p.vt_end : T);
+    if (p.vt_begin >= T && p.vt_begin != 0) return;             // clip finished in an earlier launch
+    double *__restrict__ vst = p.vstate + (int64_t)c * S;
     double myv = -INFINITY;
     if (act) {
-        const double lp = vp ? lunv[0] : lobs[b2c];
-        myv = lp + p.log_pinit;
+        if (p.vt_begin == 0) {
+            const double lp = vp ? lunv[0] : lobs[b2c];
+            myv = lp + p.log_pinit;
+        } else {
+            myv = vst[j];
+        }
         store_value(0, myv);
     }
     int par = 0;
@@ -833,7 +867,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     block_argmax(myv);
 
     int cur = 0;
-    for (int t = 1; t < T; ++t) {
+    for (int t = t_lo; t < t_hi; ++t) {
         double lp = 0.0;
         if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
 
@@ -940,6 +974,10 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         }
     }
 
+    if (t_hi < T) {                       // more launches follow: hand the column over
+        if (act) vst[j] = myv;
+        return;
+    }
     if (tid == 0) {
         int s = kg;
         for (int cc = nch - 1; cc >= 0; --cc) { bnd[cc] = s; s = cmap[(int64_t)cc * S + s]; }
@@ -1129,18 +1167,18 @@ hipError_t viterbi_configure() {
 }
 
 void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
-    if (p.n_frames == 0 || !(p.stages & 0xFu)) return;
-    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((p.n_frames + 1) / 2)), dim3(512), kFrameLds, s, p, t);
+    if (p.n_sel == 0 || !(p.stages & 0xFu)) return;
+    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((p.n_sel + 1) / 2)), dim3(512), kFrameLds, s, p, t);
 }
 void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
-    if (p.n_frames == 0) return;
-    hipLaunchKernelGGL(yin_seq_kernel, dim3((unsigned)((p.n_frames + 63) / 64)), dim3(64), 0, s, p);
+    if (p.n_sel == 0) return;
+    hipLaunchKernelGGL(yin_seq_kernel, dim3((unsigned)((p.n_sel + 63) / 64)), dim3(64), 0, s, p);
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
-    if (p.n_frames == 0) return;
+    if (p.n_sel == 0) return;
     const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1;
     const size_t lds = (size_t)(YN + 2 * KM) * 8 + (size_t)KM * 5 + 16;
-    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_frames), dim3(64), lds, s, p, t);
+    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_sel), dim3(64), lds, s, p, t);
 }
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {
     if (p.n_clips == 0) return hipSuccess;
@@ -1172,10 +1210,14 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
     hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)p.n_clips), dim3(nthr), lds, s, p, t, with_lt ? 1 : 0);
     return hipGetLastError();
 }
-void launch_finalize(const PassParams &p, const DevTables &t, hipStream_t s) {
+void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s) {
+    if (p.n_frames == 0 || !(p.stages & 0x4u)) return;
+    const unsigned g256 = (unsigned)((p.n_frames + 255) / 256);
+    hipLaunchKernelGGL(decode_kernel, dim3(g256), dim3(256), 0, s, p, t);
+}
+void launch_finalize_mel(const PassParams &p, const DevTables &, hipStream_t s) {
     if (p.n_frames == 0) return;
     const unsigned g256 = (unsigned)((p.n_frames + 255) / 256);
-    if (p.stages & 0x4u) hipLaunchKernelGGL(decode_kernel, dim3(g256), dim3(256), 0, s, p, t);
     if (p.stages & 0x3u) {
         hipLaunchKernelGGL(db_rake_kernel, dim3((unsigned)((p.n_frames + 63) / 64)), dim3(256), 0, s, p);
         if (p.stages & 0x2u) hipLaunchKernelGGL(rake_runs_kernel, dim3(g256), dim3(256), 0, s, p);
