@@ -65,6 +65,21 @@ def cpu_baseline(sample_seconds):
             "host_cpus": os.cpu_count()}
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per step of `kernel` from the committed rocprofv3 --pmc passes (profiles/
+    r1_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in KB, summed over the launches of one step;
+    FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section).  Only valid for the default workload."""
+    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")
+    if args.clips != 64 or args.clip_seconds != 180.0 or not os.path.exists(path):
+        return None, None
+    with open(path) as f:
+        pmc = json.load(f)
+    rec = pmc.get("per_step", {}).get(kernel)
+    if not rec:
+        return None, None
+    return int((2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024), "profiles/r1_pmc_hbm.json"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,7 +111,8 @@ def main():
     n_samples = np.array([len(c) for c in clips], dtype=np.int64)
     offsets = np.concatenate([[0], np.cumsum(n_samples)]).astype(np.int64)
     audio_seconds = float(n_samples.sum()) / SR
-    handle = _lib.Handle(sample_rate=SR, hop_length=HOP, device=local_rank)
+    handle = _lib.Handle(sample_rate=SR, hop_length=HOP, device=local_rank,
+                         max_frames_per_pass=max(1 << 21, int(n_samples.sum() // HOP + len(n_samples) + 1)))
     frames = int(sum(handle.frames_for(int(n)) for n in n_samples))
 
     d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
@@ -123,13 +139,14 @@ def main():
     for _ in range(args.warmup):
         step()
     handle.set_profiling(True)
-    kernel_ms = {}
+    kernel_ms, kernel_n = {}, {}
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
         for k in ("frame_fft", "yin_seq", "pyin_obs", "viterbi", "finalize"):
             kernel_ms[k] = kernel_ms.get(k, 0.0) + handle.kernel_ms(k)
+            kernel_n[k] = kernel_n.get(k, 0) + handle.kernel_launches(k)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -147,6 +164,8 @@ def main():
         dom = max(kernel_ms, key=kernel_ms.get)
         dom_ms = kernel_ms[dom]
         achieved = ALGO_BYTES_PER_AUDIO_S * audio_seconds / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        launches = max(1, kernel_n.get(dom, 0) // max(1, args.steps))
+        traffic, traffic_src = measured_traffic(dom, args)
         voiced = float(d_out["voiced_flag"].float().mean().item())
         line = {
             "metric": "audio-seconds transcribed/sec (44.1 kHz, n_fft=2048)",
@@ -162,8 +181,13 @@ def main():
                        "n_fft": 2048, "hop_length": HOP, "frames_per_gpu": frames,
                        "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
-                         "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds),
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "traffic_source": traffic_src,
+                         # the time-chunked pipeline launches the kernel once per time chunk: bytes and
+                         # duration below are per step (= sum over those launches); avg_launch_ms is what
+                         # rocprofv3 --stats reports as AverageNs
+                         "launches_per_step": launches, "avg_launch_ms": round(dom_ms / launches, 3),
+                         "algorithmic_bytes_per_step": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds),
                          "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}},
             "voiced_fraction": round(voiced, 4),
         }

@@ -91,7 +91,9 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
  * clip c occupies d_pcm[sample_offsets[c] .. sample_offsets[c+1]); `sample_offsets`
  * is a host array of n_clips+1 entries.  Outputs are device pointers.  Work is
  * enqueued on `stream` (a hipStream_t, NULL = the handle's own stream) and the
- * call returns without synchronising unless `sync` is non-zero. */
+ * call returns without synchronising unless `sync` is non-zero.  Calls on one handle are
+ * serialised by an internal mutex (the reference's servers share one engine across requests);
+ * use one handle per thread for concurrency. */
 int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                int32_t n_clips, double rake_sensitivity, uint32_t stages,
                                aegis_outputs *device_out, void *stream, int32_t sync);
@@ -136,6 +138,7 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
  * negative when unavailable.  aegis_set_profiling(h, 1) enables the events. */
 int aegis_set_profiling(aegis_handle *h, int32_t on);
 double aegis_last_kernel_ms(const aegis_handle *h, const char *name);
+int aegis_last_kernel_launches(const aegis_handle *h, const char *name); /* launches summed into the figure above */
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ class Outputs(C.Structure):
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
-           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table")
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches")
 
 _lib = None
 
@@ -75,6 +75,8 @@ def load():
     lib.aegis_set_profiling.restype = C.c_int
     lib.aegis_last_kernel_ms.argtypes = [C.c_void_p, C.c_char_p]
     lib.aegis_last_kernel_ms.restype = C.c_double
+    lib.aegis_last_kernel_launches.argtypes = [C.c_void_p, C.c_char_p]
+    lib.aegis_last_kernel_launches.restype = C.c_int
     _lib = lib
     return lib
 
@@ -164,6 +166,9 @@ class Handle:
 
     def kernel_ms(self, name):
         return float(self.lib.aegis_last_kernel_ms(self._h, name.encode()))
+
+    def kernel_launches(self, name):
+        return int(self.lib.aegis_last_kernel_launches(self._h, name.encode()))
 
     def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True):
         """clips: list of float32 1-D arrays (host).  Returns a list of per-clip dicts with the

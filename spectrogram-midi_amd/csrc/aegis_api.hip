@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -57,6 +58,8 @@ struct aegis_handle {
     bool profiling = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
     std::map<std::string, double> last_ms;
+    std::map<std::string, int> last_count;
+    std::mutex mu;                            // one analyze call at a time per handle (server.py shares an engine)
 };
 
 namespace {
@@ -117,11 +120,13 @@ void end_event(aegis_handle *h, hipStream_t s) {
 }
 void collect_events(aegis_handle *h) {
     h->last_ms.clear();
+    h->last_count.clear();
     double total = 0;
     for (auto &ev : h->events) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, ev.second.first, ev.second.second) == hipSuccess) {
             h->last_ms[ev.first] += ms;
+            h->last_count[ev.first] += 1;
             total += ms;
         }
         (void)hipEventDestroy(ev.second.first);
@@ -233,15 +238,33 @@ int aegis_set_profiling(aegis_handle *h, int32_t on) {
     return AEGIS_OK;
 }
 
+int aegis_last_kernel_launches(const aegis_handle *h, const char *name) {
+    if (!h || !name) return -1;
+    auto it = h->last_count.find(name);
+    return it == h->last_count.end() ? 0 : it->second;
+}
+
 double aegis_last_kernel_ms(const aegis_handle *h, const char *name) {
     if (!h || !name) return -1.0;
     auto it = h->last_ms.find(name);
     return it == h->last_ms.end() ? -1.0 : it->second;
 }
 
+static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
+                                 int32_t n_clips, double rake_sensitivity, uint32_t stages,
+                                 aegis_outputs *dout, void *stream_v, int32_t sync);
+
 int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                int32_t n_clips, double rake_sensitivity, uint32_t stages,
                                aegis_outputs *dout, void *stream_v, int32_t sync) {
+    if (!h) return AEGIS_ERR_INVALID;
+    std::lock_guard<std::mutex> lock(h->mu);
+    return analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+}
+
+static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
+                                 int32_t n_clips, double rake_sensitivity, uint32_t stages,
+                                 aegis_outputs *dout, void *stream_v, int32_t sync) {
     if (!h) return AEGIS_ERR_INVALID;
     if (n_clips < 0 || (n_clips > 0 && (!sample_offsets || !dout))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
     if (n_clips == 0) return AEGIS_OK;
@@ -355,9 +378,18 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
         constexpr int64_t kTimeChunk = 2048;      // multiple of kViterbiChunk
         int64_t maxF = 0;
         for (int i = 0; i < nc; ++i) maxF = std::max(maxF, frames[first + i]);
-        const int nk = (py && maxF > kTimeChunk + kTimeChunk / 2) ? (int)((maxF - 1 + kTimeChunk - 1) / kTimeChunk) : 1;
-        auto chunk_lo = [&](int k) { return k == 0 ? (int64_t)0 : 1 + k * kTimeChunk; };
-        auto chunk_hi = [&](int k) { return k == nk - 1 ? maxF : 1 + (k + 1) * kTimeChunk; };
+        // chunk boundaries: frame 0, then 1 + (multiple of kViterbiChunk) so that every launch starts
+        // on a back-pointer-map boundary.  The first chunks are short (256, 768 steps) so the
+        // Viterbi stream starts early; nothing overlaps the first chunk's frame stage.
+        std::vector<int64_t> cb{0};
+        if (py && maxF > kTimeChunk + kTimeChunk / 2) {
+            for (int64_t e : {(int64_t)256, (int64_t)1024}) cb.push_back(1 + e);
+            while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) cb.push_back(cb.back() + kTimeChunk);
+        }
+        cb.push_back(maxF);
+        const int nk = (int)cb.size() - 1;
+        auto chunk_lo = [&](int k) { return cb[k]; };
+        auto chunk_hi = [&](int k) { return cb[k + 1]; };
         m.sel_off.assign((size_t)nk * (nc + 1), 0);
         for (int k = 0; k < nk; ++k)
             for (int i = 0; i < nc; ++i) {
@@ -422,6 +454,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if (n_clips == 0) return AEGIS_OK;
     if (stages & AEGIS_STAGE_RAKE) stages |= AEGIS_STAGE_MEL;
     if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     std::vector<int64_t> off(n_clips + 1, 0);
     int64_t F = 0;
@@ -446,8 +479,8 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if ((stages & AEGIS_STAGE_RMS) && out->rms) { if ((rc = ensure(h, h->io_rms, F * 4))) return rc; d.rms = static_cast<float *>(h->io_rms.p); }
     if ((stages & AEGIS_STAGE_RAKE) && out->rake_mask) { if ((rc = ensure(h, h->io_rake, F))) return rc; d.rake_mask = static_cast<uint8_t *>(h->io_rake.p); }
     if ((stages & AEGIS_STAGE_MEL) && out->S_dB) { if ((rc = ensure(h, h->io_sdb, F * nm * 4))) return rc; d.S_dB = static_cast<float *>(h->io_sdb.p); }
-    rc = aegis_analyze_batch_device(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
-                                    rake_sensitivity, stages, &d, s, 0);
+    rc = analyze_device_locked(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
+                               rake_sensitivity, stages, &d, s, 0);
     if (rc != AEGIS_OK) return rc;
     if (d.f0) HIPCHK(h, hipMemcpyAsync(out->f0, d.f0, F * 8, hipMemcpyDeviceToHost, s));
     if (d.voiced_flag) HIPCHK(h, hipMemcpyAsync(out->voiced_flag, d.voiced_flag, F, hipMemcpyDeviceToHost, s));
@@ -467,6 +500,7 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
     if (n_mels <= 0 || n_frames < 0 || (n_frames > 0 && (!S_dB || !mask_out))) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
     if (n_frames == 0) return AEGIS_OK;
     if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     int rc;
     const size_t img = (size_t)n_mels * n_frames * 4;
