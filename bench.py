@@ -89,6 +89,8 @@ def main():
     ap.add_argument("--clip-seconds", type=float, default=180.0)
     ap.add_argument("--cpu-sample-seconds", type=float, default=60.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="test hook: every rank uses cuda:0 and the gloo backend (multi-rank path on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -99,11 +101,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the analyze path has no CPU fallback")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    red_dev = torch.device("cpu") if args.rehearse_on_one_gpu else dev     # where the timing reductions live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from spectrogram_midi_amd import _lib
 
@@ -150,10 +158,10 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        tot = torch.tensor([audio_seconds], dtype=torch.float64, device=dev)
+        tot = torch.tensor([audio_seconds], dtype=torch.float64, device=red_dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         total_audio = float(tot.item())
     else:

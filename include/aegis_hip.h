@@ -104,6 +104,39 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
 int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int64_t n_frames,
                         double broadband_threshold_ratio, uint8_t *mask_out);
 
+/* --- v2 "financial" trend filters on pitch tracks -------------------
+ * One op-coded entry over a ragged batch of float64 series in host memory: series i is
+ * x[offsets[i] .. offsets[i+1]) (NaN = unvoiced); outputs are host arrays of offsets[n_series]
+ * elements (double unless noted).  Blocking.  Each op replaces the reference method named:
+ *
+ *  op                        params                         outs
+ *  AEGIS_TREND_SMA           window                         out          FinancialPitchAnalyzer.simple_moving_average (financial_analysis.py:45-69)
+ *  AEGIS_TREND_EMA           span                           out          .exponential_moving_average (:71-107)
+ *  AEGIS_TREND_BOLLINGER     window, num_std                ma,upper,lower   .bollinger_bands (:113-146)
+ *  AEGIS_TREND_ARTICULATION  window, sensitivity            int8 codes   .detect_articulation_bollinger (:148-197): 0 None 1 normal 2 bend 3 vibrato 4 noise
+ *  AEGIS_TREND_MACD          fast, slow, signal             macd,signal,hist .macd (:203-226)
+ *  AEGIS_TREND_SLIDES        threshold                      int8 codes   .detect_slides_macd (:228-268): 0 None 1 normal 2 slide_up 3 slide_down
+ *  AEGIS_TREND_RSI           period                         out          .rsi (:274-320)
+ *  AEGIS_TREND_SAVGOL        window, symmetric, coef[window] out         FinancialNoiseFilters.savitzky_golay (financial_filters.py:25-59); coef = reversed scipy savgol_coeffs
+ *  AEGIS_TREND_KALMAN        process_var, measurement_var   out          .kalman_filter (:62-99)
+ *  AEGIS_TREND_HOLT          alpha, beta                    out          .holt_winters (:102-141)
+ *  AEGIS_TREND_CONSENSUS     k  (x = k stacked rows, n_series = 1)  median, confidence   multi_filter_consensus (:256-298)
+ *
+ * A series shorter than the window is AEGIS_ERR_INVALID for SMA/Bollinger (the reference raises IndexError). */
+#define AEGIS_TREND_SMA 1
+#define AEGIS_TREND_EMA 2
+#define AEGIS_TREND_BOLLINGER 3
+#define AEGIS_TREND_ARTICULATION 4
+#define AEGIS_TREND_MACD 5
+#define AEGIS_TREND_SLIDES 6
+#define AEGIS_TREND_RSI 7
+#define AEGIS_TREND_SAVGOL 8
+#define AEGIS_TREND_KALMAN 9
+#define AEGIS_TREND_HOLT 10
+#define AEGIS_TREND_CONSENSUS 11
+int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
+                const double *params, int32_t n_params, void *const *outs, int32_t n_outs);
+
 /* --- introspection used by the tests (no reference counterpart) ------------- */
 
 /* Host-side copies of the tables the kernels use.  `name` is one of

@@ -22,10 +22,15 @@ PARITY PIN STATUS
   under NumPy-1.x dtype rules (np.fft upcasts float32 input to float64), is
   stamped "librosa-0.10-semantics" in every fixture, and is anchored by analytic
   known answers (tests/test_oracle_known_answers.py).
+* v2 trend filters and harmonic analysis (reference `aegis_engine_core_v2/financial_analysis.py`,
+  `financial_filters.py`, `harmonic_analysis.py`): PINNED, and the oracle IS
+  the reference -- `tests/golden/make_v2_golden.py` imports those NumPy/SciPy-only modules and freezes
+  their outputs (`v2_trend_golden.npz`, `v2_harmonic_golden.json`); no restatement stands in between.
+  Only `detect_slides_macd` needed a one-formula `librosa.hz_to_midi` stub.
 * `oracle.events` / `oracle.smf` (reference `aegis_engine_core/midi_logic.py`,
   `aegis_engine.py:98-179`; mido un-vendored): unpinned for the same reason;
   the SMF byte layout follows the Standard MIDI File 1.0 spec as mido 1.3
-  writes it (running status off, explicit end_of_track).
+  writes it (running status inside a track, end_of_track appended).
 """
 
 SEMANTICS = "librosa-0.10-semantics/numpy1-dtypes"

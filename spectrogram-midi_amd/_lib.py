@@ -9,6 +9,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AEGIS_HIP_LIB", os.path.join(_HERE, "libaegis_hip.so"))
 
 STAGE_MEL, STAGE_RAKE, STAGE_PYIN, STAGE_RMS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
+(TREND_SMA, TREND_EMA, TREND_BOLLINGER, TREND_ARTICULATION, TREND_MACD, TREND_SLIDES, TREND_RSI, TREND_SAVGOL,
+ TREND_KALMAN, TREND_HOLT, TREND_CONSENSUS) = range(1, 12)
 OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95
 
 
@@ -31,7 +33,7 @@ class Outputs(C.Structure):
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
-           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches")
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend")
 
 _lib = None
 
@@ -63,6 +65,9 @@ def load():
     lib.aegis_analyze_batch_device.restype = C.c_int
     lib.aegis_rake_patterns.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_double, C.c_void_p]
     lib.aegis_rake_patterns.restype = C.c_int
+    lib.aegis_trend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                C.POINTER(C.c_void_p), C.c_int32]
+    lib.aegis_trend.restype = C.c_int
     lib.aegis_set_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_set_table.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -219,6 +224,26 @@ class Handle:
         out = np.zeros(F, np.uint8)
         self._check(self.lib.aegis_rake_patterns(self._h, S.ctypes.data, n_mels, F, float(ratio), out.ctypes.data))
         return out.astype(bool)
+
+    def trend(self, op, series, params, n_out=1, out_dtype=np.float64, stacked_rows=None):
+        """aegis_trend over a list of float64 series (or one `stacked_rows` x len array for the
+        consensus op).  Returns a list (per output) of lists (per series) of arrays."""
+        if stacked_rows is not None:
+            x = np.ascontiguousarray(series, dtype=np.float64).reshape(stacked_rows, -1)
+            lens = [x.shape[1]]
+            flat = x.ravel()
+        else:
+            series = [np.ascontiguousarray(s, dtype=np.float64) for s in series]
+            lens = [len(s) for s in series]
+            flat = np.concatenate(series) if series else np.zeros(0)
+        off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+        total = int(off[-1])
+        par = np.ascontiguousarray(params, dtype=np.float64)
+        outs = [np.empty(total, dtype=out_dtype) for _ in range(n_out)]
+        ptrs = (C.c_void_p * n_out)(*[o.ctypes.data for o in outs])
+        self._check(self.lib.aegis_trend(self._h, int(op), flat.ctypes.data, off.ctypes.data, len(lens),
+                                         par.ctypes.data, len(par), ptrs, n_out))
+        return [[o[off[i]:off[i + 1]] for i in range(len(lens))] for o in outs]
 
     def analyze_batch_device(self, d_pcm_ptr, sample_offsets, outputs, rake_sensitivity=0.6,
                              stages=STAGE_ALL, stream=None, sync=True):

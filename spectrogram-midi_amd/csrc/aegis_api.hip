@@ -17,6 +17,7 @@
 #include "../../include/aegis_hip.h"
 #include "kernels.h"
 #include "tables.h"
+#include "trend.h"
 
 using namespace aegis;
 
@@ -49,6 +50,7 @@ struct aegis_handle {
     // workspace (grow-only)
     DevBuf acf, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
     DevBuf sample_off, frame_off, order, sel_off, vstate;
+    DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
     DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb;
     int32_t lag_stride = 0, yin_stride = 0, obs_stride = 0;
     std::vector<PassMeta> metas;
@@ -219,7 +221,8 @@ void aegis_destroy(aegis_handle *h) {
     for (void *p : h->table_allocs) (void)hipFree(p);
     for (DevBuf *b : {&h->acf, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
                       &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
-                      &h->order, &h->sel_off, &h->vstate, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
+                      &h->order, &h->sel_off, &h->vstate, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
+                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb})
         free_buf(*b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -515,6 +518,134 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
                         static_cast<uint8_t *>(h->io_rake.p), s);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(mask_out, h->io_rake.p, n_frames, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return AEGIS_OK;
+}
+
+int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
+                const double *params, int32_t n_params, void *const *outs, int32_t n_outs) {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_series < 0 || (n_series > 0 && (!x || !offsets)) || !outs || n_params < 0 || (n_params > 0 && !params)) {
+        h->err = "bad argument"; return AEGIS_ERR_INVALID;
+    }
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    auto need = [&](int np, int no) {
+        if (n_params < np || n_outs < no) { h->err = "op needs " + std::to_string(np) + " params and " + std::to_string(no) + " outputs"; return false; }
+        for (int i = 0; i < no; ++i) if (!outs[i]) { h->err = "null output"; return false; }
+        return true;
+    };
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    int64_t total = n_series > 0 ? offsets[n_series] : 0;
+    int64_t n_in = total;
+    if (op == AEGIS_TREND_CONSENSUS) {       // x = k stacked rows of one series
+        if (!need(1, 2) || n_series != 1) { if (n_series != 1) h->err = "consensus takes one series"; return AEGIS_ERR_INVALID; }
+        const int k = (int)params[0];
+        if (k < 1 || k > 8) { h->err = "consensus of 1..8 filters"; return AEGIS_ERR_INVALID; }
+        n_in = total * k;
+    }
+    if (total == 0) return AEGIS_OK;
+    for (int i = 0; i < n_series; ++i)
+        if (offsets[i + 1] < offsets[i]) { h->err = "offsets must be non-decreasing"; return AEGIS_ERR_INVALID; }
+#define ENS(buf, bytes) if ((rc = ensure(h, h->buf, (size_t)(bytes))) != AEGIS_OK) return rc
+    ENS(t_x, n_in * 8); ENS(t_off, (n_series + 1) * 8);
+    ENS(t_a, total * 8); ENS(t_b, total * 8); ENS(t_c, total * 8); ENS(t_d, total * 8); ENS(t_e, total * 8);
+    ENS(t_i8, total); ENS(t_i64a, total * 8); ENS(t_i64b, (n_series + 1) * 8);
+#undef ENS
+    HIPCHK(h, hipMemcpyAsync(h->t_x.p, x, n_in * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->t_off.p, offsets, (n_series + 1) * 8, hipMemcpyHostToDevice, s));
+    TrendArgs a{static_cast<const double *>(h->t_x.p), static_cast<const int64_t *>(h->t_off.p), n_series, total};
+    double *A = static_cast<double *>(h->t_a.p), *B = static_cast<double *>(h->t_b.p), *Cc = static_cast<double *>(h->t_c.p);
+    double *D = static_cast<double *>(h->t_d.p), *E = static_cast<double *>(h->t_e.p);
+    int8_t *I8 = static_cast<int8_t *>(h->t_i8.p);
+    auto back = [&](void *dst, const void *src, size_t bytes) { return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s); };
+    auto min_len = [&]() { int64_t m = INT64_MAX; for (int i = 0; i < n_series; ++i) m = std::min(m, offsets[i + 1] - offsets[i]); return m; };
+    switch (op) {
+    case AEGIS_TREND_SMA: {
+        if (!need(1, 1)) return AEGIS_ERR_INVALID;
+        const int w = (int)params[0];
+        if (w < 1 || min_len() < w) { h->err = "series shorter than the window (the reference raises IndexError)"; return AEGIS_ERR_INVALID; }
+        trend_sma(a, w, A, s);
+        HIPCHK(h, back(outs[0], A, total * 8));
+        break;
+    }
+    case AEGIS_TREND_EMA: {
+        if (!need(1, 1)) return AEGIS_ERR_INVALID;
+        trend_ema(a, (int)params[0], A, s);
+        HIPCHK(h, back(outs[0], A, total * 8));
+        break;
+    }
+    case AEGIS_TREND_BOLLINGER:
+    case AEGIS_TREND_ARTICULATION: {
+        const bool art = op == AEGIS_TREND_ARTICULATION;
+        if (!need(2, art ? 1 : 3)) return AEGIS_ERR_INVALID;
+        const int w = (int)params[0];
+        if (w < 1 || w > 128 || min_len() < w) { h->err = "window must be 1..128 and not longer than any series"; return AEGIS_ERR_INVALID; }
+        trend_bollinger(a, w, params[1], A, B, Cc, s);
+        if (art) {
+            trend_articulation(a, B, Cc, I8, s);
+            HIPCHK(h, back(outs[0], I8, total));
+        } else {
+            HIPCHK(h, back(outs[0], A, total * 8)); HIPCHK(h, back(outs[1], B, total * 8)); HIPCHK(h, back(outs[2], Cc, total * 8));
+        }
+        break;
+    }
+    case AEGIS_TREND_MACD: {
+        if (!need(3, 3)) return AEGIS_ERR_INVALID;
+        trend_macd(a, (int)params[0], (int)params[1], (int)params[2], A, B, Cc, s);
+        HIPCHK(h, back(outs[0], A, total * 8)); HIPCHK(h, back(outs[1], B, total * 8)); HIPCHK(h, back(outs[2], Cc, total * 8));
+        break;
+    }
+    case AEGIS_TREND_SLIDES: {      // detect_slides_macd: hz_to_midi, macd(5, 20, 9), threshold test
+        if (!need(1, 1)) return AEGIS_ERR_INVALID;
+        trend_semitones(a.x, total, D, s);
+        TrendArgs st{D, a.off, n_series, total};
+        trend_macd(st, 5, 20, 9, A, B, Cc, s);
+        trend_slides(A, Cc, total, params[0], I8, s);
+        HIPCHK(h, back(outs[0], I8, total));
+        break;
+    }
+    case AEGIS_TREND_RSI: {
+        if (!need(1, 1)) return AEGIS_ERR_INVALID;
+        const int per = (int)params[0];
+        if (per < 1 || per > 128) { h->err = "rsi period must be 1..128"; return AEGIS_ERR_INVALID; }
+        trend_rsi(a, per, A, s);
+        HIPCHK(h, back(outs[0], A, total * 8));
+        break;
+    }
+    case AEGIS_TREND_SAVGOL: {      // params: window, symmetric flag, then `window` reversed coefficients
+        if (n_params < 2 || !need(2 + (int)params[0], 1)) { h->err = "savgol params: window, symmetric, coefficients"; return AEGIS_ERR_INVALID; }
+        const int w = (int)params[0];
+        if (w < 1 || (w & 1) == 0 || w > 255) { h->err = "savgol window must be odd, 1..255"; return AEGIS_ERR_INVALID; }
+        HIPCHK(h, hipMemcpyAsync(E, params + 2, (size_t)w * 8, hipMemcpyHostToDevice, s));
+        trend_savgol(a, E, w, (int)params[1], B, static_cast<int64_t *>(h->t_i64a.p), static_cast<int64_t *>(h->t_i64b.p), A, s);
+        HIPCHK(h, back(outs[0], A, total * 8));
+        break;
+    }
+    case AEGIS_TREND_KALMAN: {
+        if (!need(2, 1)) return AEGIS_ERR_INVALID;
+        trend_kalman(a, params[0], params[1], A, s);
+        HIPCHK(h, back(outs[0], A, total * 8));
+        break;
+    }
+    case AEGIS_TREND_HOLT: {
+        if (!need(2, 1)) return AEGIS_ERR_INVALID;
+        trend_holt(a, params[0], params[1], A, s);
+        HIPCHK(h, back(outs[0], A, total * 8));
+        break;
+    }
+    case AEGIS_TREND_CONSENSUS: {
+        trend_consensus(a.x, (int)params[0], total, A, B, s);
+        HIPCHK(h, back(outs[0], A, total * 8)); HIPCHK(h, back(outs[1], B, total * 8));
+        break;
+    }
+    default:
+        h->err = "unknown trend op " + std::to_string(op);
+        return AEGIS_ERR_INVALID;
+    }
+    HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;
 }

@@ -1,0 +1,384 @@
+// Trend-filter kernels for the v2 "financial" pitch analysis:
+// /root/reference/aegis_engine_core_v2/financial_analysis.py (SMA, EMA, Bollinger, MACD, RSI,
+// articulation / slide state machines) and financial_filters.py (Savitzky-Golay on NaN-compacted
+// samples, scalar Kalman, Holt, nan-median consensus), over ragged batches of float64 series.
+//
+// The reference's recurrences (EMA, Wilder RSI, Kalman, Holt, the state machines) are strictly
+// sequential Python loops: each series is walked by ONE lane in the same order with the same
+// float64 operations (-ffp-contract=off), so those outputs are bit-identical; the windowed
+// operators (SMA, rolling std, Savitzky-Golay FIR, consensus) are one element per thread and
+// reproduce NumPy's summation orders (pairwise sums, ndimage's symmetric correlate).
+#include <hip/hip_runtime.h>
+
+#include <cfloat>
+#include <cmath>
+#include <cstdint>
+
+#include "trend.h"
+
+namespace aegis {
+
+__device__ __forceinline__ int series_of(const int64_t *__restrict__ off, int n, int64_t i) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (off[mid] <= i) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// numpy pairwise_sum for n <= 128 (umath loops), reading a[i] through `get`
+template <typename F>
+__device__ __forceinline__ double np_sum_small(F get, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += get(i);
+        return res;
+    }
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = get(k);
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] += get(i + k);
+    }
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += get(i);
+    return res;
+}
+
+// ---- a13: simple_moving_average (financial_analysis.py:45-69) -------------------------------
+// np.convolve(nan->0, ones(w)/w, 'same') then NaN restored.
+__global__ void sma_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+                           int64_t total, int w, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int s = series_of(off, n_series, i);
+    const int64_t lo = off[s], hi = off[s + 1];
+    const double xi = x[i];
+    if (xi != xi) { out[i] = NAN; return; }
+    const double kv = 1.0 / (double)w;
+    const int64_t m1 = i + (w - 1) / 2, m0 = m1 - (w - 1);
+    double acc = 0.0;
+    for (int64_t m = m0 > lo ? m0 : lo; m <= m1 && m < hi; ++m) {
+        const double v = x[m];
+        acc += (v != v ? 0.0 : v) * kv;
+    }
+    out[i] = acc;
+}
+
+// ---- a14: exponential_moving_average (financial_analysis.py:71-107), one lane per series ----
+__device__ void ema_series(const double *__restrict__ x, int64_t n, int span, double *__restrict__ out) {
+    const double alpha = 2.0 / (double)(span + 1);
+    double prev = NAN;
+    bool started = false;
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = x[i];
+        double e = NAN;
+        if (v == v) {
+            if (!started) { e = v; started = true; }
+            else if (prev != prev) e = v;
+            else e = alpha * v + (1 - alpha) * prev;
+        }
+        out[i] = e;
+        prev = e;
+    }
+}
+
+__global__ void ema_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int span,
+                           double *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    ema_series(x + off[s], off[s + 1] - off[s], span, out + off[s]);
+}
+
+// ---- a15: bollinger_bands (financial_analysis.py:113-146): needs ma (SMA) computed before ----
+__global__ void bollinger_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+                                 int64_t total, int w, double num_std, const double *__restrict__ ma,
+                                 double *__restrict__ upper, double *__restrict__ lower) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int s = series_of(off, n_series, i);
+    const int64_t lo = off[s];
+    int64_t a = i - w + 1;
+    if (a < lo) a = lo;
+    // np.std of the non-NaN values of x[a..i] (population), only when there are at least two
+    double buf[128];
+    int cnt = 0;
+    for (int64_t m = a; m <= i; ++m) { const double v = x[m]; if (v == v && cnt < 128) buf[cnt++] = v; }
+    double sd = NAN;
+    if (cnt > 1) {
+        const double mean = np_sum_small([&](int k) { return buf[k]; }, cnt) / (double)cnt;
+        const double var = np_sum_small([&](int k) { const double d = buf[k] - mean; return d * d; }, cnt) / (double)cnt;
+        sd = sqrt(var);
+    }
+    upper[i] = ma[i] + (num_std * sd);
+    lower[i] = ma[i] - (num_std * sd);
+}
+
+// ---- detect_articulation_bollinger state machine (financial_analysis.py:148-197) -------------
+// codes: 0 None, 1 normal, 2 bend, 3 vibrato, 4 noise
+__global__ void articulation_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+                                    const double *__restrict__ upper, const double *__restrict__ lower,
+                                    int8_t *__restrict__ codes) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    int prev = 0, vib = 0;   // state: 0 normal, 1 above, 2 below
+    for (int64_t i = off[s]; i < off[s + 1]; ++i) {
+        const double v = x[i];
+        if (v != v) { codes[i] = 0; continue; }
+        const int st = v > upper[i] ? 1 : (v < lower[i] ? 2 : 0);
+        if (prev != st && prev != 0) ++vib; else vib = 0;
+        codes[i] = vib >= 2 ? 3 : (st == 1 ? 2 : (st == 2 ? 4 : 1));
+        prev = st;
+    }
+}
+
+// ---- a16: macd (financial_analysis.py:203-226) ------------------------------------------------
+__global__ void macd_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int fast,
+                            int slow, int sig, double *__restrict__ macd, double *__restrict__ signal,
+                            double *__restrict__ hist) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    const int64_t o = off[s], n = off[s + 1] - o;
+    ema_series(x + o, n, fast, macd + o);       // macd <- ema_fast
+    ema_series(x + o, n, slow, hist + o);       // hist <- ema_slow (scratch)
+    for (int64_t i = 0; i < n; ++i) macd[o + i] = macd[o + i] - hist[o + i];
+    ema_series(macd + o, n, sig, signal + o);
+    for (int64_t i = 0; i < n; ++i) hist[o + i] = macd[o + i] - signal[o + i];
+}
+
+// Hz -> MIDI semitones for detect_slides_macd (financial_analysis.py:242-248; librosa.hz_to_midi)
+__global__ void semitone_kernel(const double *__restrict__ x, int64_t total, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double v = x[i];
+    out[i] = v != v ? NAN : 12 * (log2(v) - log2(440.0)) + 69;
+}
+
+// codes: 0 None, 1 normal, 2 slide_up, 3 slide_down (financial_analysis.py:254-268)
+__global__ void slides_kernel(const double *__restrict__ macd, const double *__restrict__ hist, int64_t total,
+                              double thr, int8_t *__restrict__ codes) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double m = macd[i], h = hist[i];
+    int8_t c;
+    if (m != m) c = 0;
+    else if (m > thr && h > 0) c = 2;
+    else if (m < -thr && h < 0) c = 3;
+    else c = 1;
+    codes[i] = c;
+}
+
+// ---- rsi (financial_analysis.py:274-320), Wilder smoothing, one lane per series ---------------
+__global__ void rsi_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int period,
+                           double *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    const double *d = x + off[s];
+    double *o = out + off[s];
+    const int64_t n = off[s + 1] - off[s];
+    for (int64_t i = 0; i < n; ++i) o[i] = 50.0;
+    if (n - 1 < period || period < 1) return;
+    auto gain = [&](int64_t i) { const double dl = d[i + 1] - d[i]; return dl > 0 ? dl : 0.0; };
+    auto loss = [&](int64_t i) { const double dl = d[i + 1] - d[i]; return dl < 0 ? -dl : 0.0; };
+    double ag, al;
+    if (period <= 128) {
+        ag = np_sum_small([&](int k) { return gain(k); }, period) / (double)period;
+        al = np_sum_small([&](int k) { return loss(k); }, period) / (double)period;
+    } else {
+        ag = al = NAN;   // host rejects period > 128
+    }
+    for (int64_t i = period; i < n; ++i) {
+        if (i > period) {
+            ag = (ag * (period - 1) + gain(i - 1)) / period;
+            al = (al * (period - 1) + loss(i - 1)) / period;
+        }
+        if (al == 0) o[i] = 100;
+        else { const double rs = ag / al; o[i] = 100 - (100 / (1 + rs)); }
+    }
+}
+
+// ---- a17: Savitzky-Golay on NaN-compacted samples (financial_filters.py:25-59) ----------------
+// pass 1 (one lane per series): compact valid samples, remember their positions
+__global__ void compact_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+                               double *__restrict__ cx, int64_t *__restrict__ cpos, int64_t *__restrict__ ccount) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    int64_t k = off[s];
+    for (int64_t i = off[s]; i < off[s + 1]; ++i) {
+        const double v = x[i];
+        if (v == v) { cx[k] = v; cpos[k] = i; ++k; }
+    }
+    ccount[s] = k - off[s];
+}
+
+// pass 2: scipy.signal.savgol_filter(valid, window, polyorder, mode='nearest') =
+// ndimage.correlate1d with the reversed coefficients; `coef` arrives already reversed, centre at
+// coef[half].  Sum order follows NI_Correlate1D: symmetric kernels fold the two sides.  Two launches:
+// initialise the output (NaN, or the input when a series has no valid sample), then filter + scatter.
+__global__ void savgol_init_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+                                   int64_t total, const int64_t *__restrict__ ccount, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int s = series_of(off, n_series, i);
+    out[i] = ccount[s] == 0 ? x[i] : NAN;
+}
+
+__global__ void savgol_apply_kernel(const int64_t *__restrict__ off, int n_series, int64_t total,
+                                    const double *__restrict__ cx, const int64_t *__restrict__ cpos,
+                                    const int64_t *__restrict__ ccount, const double *__restrict__ coef, int window,
+                                    int symmetric, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int s = series_of(off, n_series, i);
+    const int64_t o = off[s], nv = ccount[s];
+    const int64_t k = i - o;
+    if (nv <= window || k >= nv) return;
+    const int half = window / 2;
+    auto at = [&](int64_t q) { q = q < 0 ? 0 : (q >= nv ? nv - 1 : q); return cx[o + q]; };
+    const double *fw = coef + half;
+    double tmp;
+    if (symmetric) {
+        tmp = at(k) * fw[0];
+        for (int jj = -half; jj < 0; ++jj) tmp += (at(k + jj) + at(k - jj)) * fw[jj];
+    } else {
+        tmp = at(k + half) * fw[half];
+        for (int jj = -half; jj < half; ++jj) tmp += at(k + jj) * fw[jj];
+    }
+    out[cpos[o + k]] = tmp;
+}
+
+// ---- Kalman (financial_filters.py:62-99) and Holt (:102-141), one lane per series -------------
+__global__ void kalman_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, double q,
+                              double r, double *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    double x_est = NAN, p_est = 1.0;
+    bool started = false;
+    for (int64_t i = off[s]; i < off[s + 1]; ++i) {
+        const double v = x[i];
+        if (v != v) { out[i] = NAN; continue; }
+        if (!started) { x_est = v; started = true; }
+        const double x_pred = x_est, p_pred = p_est + q;
+        const double k = p_pred / (p_pred + r);
+        x_est = x_pred + k * (v - x_pred);
+        p_est = (1 - k) * p_pred;
+        out[i] = x_est;
+    }
+}
+
+__global__ void holt_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, double alpha,
+                            double beta, double *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_series) return;
+    const int64_t lo = off[s], hi = off[s + 1];
+    double first = NAN, second = NAN;
+    int found = 0;
+    for (int64_t i = lo; i < hi && found < 2; ++i) {
+        const double v = x[i];
+        if (v == v) { if (found == 0) first = v; else second = v; ++found; }
+    }
+    if (found < 2) {                 // fewer than two valid samples: the input comes back unchanged
+        for (int64_t i = lo; i < hi; ++i) out[i] = x[i];
+        return;
+    }
+    double level = first, trend = second - first;
+    for (int64_t i = lo; i < hi; ++i) {
+        const double v = x[i];
+        if (v != v) { out[i] = NAN; continue; }
+        const double forecast = level + trend;
+        const double level_new = alpha * v + (1 - alpha) * forecast;
+        const double trend_new = beta * (level_new - level) + (1 - beta) * trend;
+        out[i] = level_new;
+        level = level_new;
+        trend = trend_new;
+    }
+}
+
+// ---- multi_filter_consensus (financial_filters.py:256-298): nanmedian / 1/(1+nanstd) ----------
+__global__ void consensus_kernel(const double *__restrict__ stacked, int k, int64_t len, double *__restrict__ med,
+                                 double *__restrict__ conf) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    double v[8];
+    int cnt = 0;
+    double sum = 0.0;                       // np.sum over axis 0 of the NaN->0 copy: ((0 + r0) + r1) + ...
+    for (int r = 0; r < k; ++r) {
+        const double a = stacked[(int64_t)r * len + i];
+        const bool ok = a == a;
+        sum += ok ? a : 0.0;
+        if (ok && cnt < 8) v[cnt++] = a;
+    }
+    if (cnt == 0) { med[i] = NAN; conf[i] = NAN; return; }
+    // nanstd
+    const double avg = sum / (double)cnt;
+    double sq = 0.0;
+    for (int r = 0; r < k; ++r) {
+        const double a = stacked[(int64_t)r * len + i];
+        const double d = (a == a) ? a - avg : 0.0;
+        sq += d * d;
+    }
+    const double sd = sqrt(sq / (double)cnt);
+    conf[i] = 1.0 / (1.0 + sd);
+    // nanmedian: insertion sort of <= 8 values
+    for (int a = 1; a < cnt; ++a) {
+        const double key = v[a];
+        int b = a - 1;
+        while (b >= 0 && v[b] > key) { v[b + 1] = v[b]; --b; }
+        v[b + 1] = key;
+    }
+    med[i] = (cnt & 1) ? v[cnt / 2] : (v[cnt / 2 - 1] == v[cnt / 2] ? v[cnt / 2] : (v[cnt / 2 - 1] + v[cnt / 2]) / 2.0);
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+static inline unsigned blocks(int64_t n, int t) { return (unsigned)((n + t - 1) / t); }
+
+void trend_sma(const TrendArgs &a, int w, double *out, hipStream_t s) {
+    if (a.total) hipLaunchKernelGGL(sma_kernel, dim3(blocks(a.total, 256)), dim3(256), 0, s, a.x, a.off, a.n_series, a.total, w, out);
+}
+void trend_ema(const TrendArgs &a, int span, double *out, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(ema_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, span, out);
+}
+void trend_bollinger(const TrendArgs &a, int w, double k, double *ma, double *up, double *lo, hipStream_t s) {
+    if (!a.total) return;
+    trend_sma(a, w, ma, s);
+    hipLaunchKernelGGL(bollinger_kernel, dim3(blocks(a.total, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, a.total, w, k, ma, up, lo);
+}
+void trend_articulation(const TrendArgs &a, const double *up, const double *lo, int8_t *codes, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(articulation_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, up, lo, codes);
+}
+void trend_macd(const TrendArgs &a, int fast, int slow, int sig, double *m, double *sg, double *h, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(macd_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, fast, slow, sig, m, sg, h);
+}
+void trend_semitones(const double *x, int64_t total, double *out, hipStream_t s) {
+    if (total) hipLaunchKernelGGL(semitone_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, x, total, out);
+}
+void trend_slides(const double *macd, const double *hist, int64_t total, double thr, int8_t *codes, hipStream_t s) {
+    if (total) hipLaunchKernelGGL(slides_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, macd, hist, total, thr, codes);
+}
+void trend_rsi(const TrendArgs &a, int period, double *out, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(rsi_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, period, out);
+}
+void trend_savgol(const TrendArgs &a, const double *coef_rev, int window, int symmetric, double *cx, int64_t *cpos,
+                  int64_t *ccount, double *out, hipStream_t s) {
+    if (!a.total) return;
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, cx, cpos, ccount);
+    hipLaunchKernelGGL(savgol_init_kernel, dim3(blocks(a.total, 256)), dim3(256), 0, s, a.x, a.off, a.n_series, a.total, ccount, out);
+    hipLaunchKernelGGL(savgol_apply_kernel, dim3(blocks(a.total, 256)), dim3(256), 0, s, a.off, a.n_series, a.total, cx, cpos, ccount,
+                       coef_rev, window, symmetric, out);
+}
+void trend_kalman(const TrendArgs &a, double q, double r, double *out, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(kalman_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, q, r, out);
+}
+void trend_holt(const TrendArgs &a, double alpha, double beta, double *out, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(holt_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, alpha, beta, out);
+}
+void trend_consensus(const double *stacked, int k, int64_t len, double *med, double *conf, hipStream_t s) {
+    if (len) hipLaunchKernelGGL(consensus_kernel, dim3(blocks(len, 256)), dim3(256), 0, s, stacked, k, len, med, conf);
+}
+
+}  // namespace aegis

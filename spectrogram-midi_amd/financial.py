@@ -1,0 +1,145 @@
+"""v2 "financial" pitch analysis on the GPU: the reference's `FinancialPitchAnalyzer`
+(/root/reference/aegis_engine_core_v2/financial_analysis.py:25-423) and `FinancialNoiseFilters` /
+`multi_filter_consensus` (financial_filters.py:25-141, 256-298) with the same class, method and keyword
+names, return shapes and quirks; every array operation is one `aegis_trend` call (csrc/trend.hip)."""
+import numpy as np
+import scipy.signal
+
+from . import _lib
+
+_ARTICULATIONS = (None, "normal", "bend", "vibrato", "noise")
+_SLIDES = (None, "normal", "slide_up", "slide_down")
+_handles = {}
+
+
+def _handle(device=0):
+    if device not in _handles:
+        _handles[device] = _lib.Handle(device=device, scipy_tables=False)
+    return _handles[device]
+
+
+def _one(op, data, params, n_out=1, dtype=np.float64, device=0):
+    res = _handle(device).trend(op, [np.asarray(data, dtype=np.float64)], params, n_out=n_out, out_dtype=dtype)
+    return [r[0] for r in res]
+
+
+class FinancialNoiseFilters:
+    """financial_filters.py:17-141 (the dead-code ATR / Ichimoku / stochastic helpers are not part of the
+    analyze path and are not provided)."""
+    device = 0
+
+    @staticmethod
+    def savitzky_golay(data, window=11, polyorder=3):
+        data = np.asarray(data, dtype=np.float64)
+        # scipy.signal.savgol_filter = correlate with the reversed coefficients; ndimage folds the
+        # two sides when the kernel is symmetric to DBL_EPSILON (ni_filters.c) -- same test here
+        coef = scipy.signal.savgol_coeffs(window, polyorder)[::-1]
+        symmetric = bool(np.all(np.abs(coef - coef[::-1]) <= np.finfo(float).eps))
+        return _one(_lib.TREND_SAVGOL, data, [window, int(symmetric), *coef], device=FinancialNoiseFilters.device)[0]
+
+    @staticmethod
+    def kalman_filter(data, process_variance=1e-5, measurement_variance=1e-1):
+        return _one(_lib.TREND_KALMAN, data, [process_variance, measurement_variance], device=FinancialNoiseFilters.device)[0]
+
+    @staticmethod
+    def holt_winters(data, alpha=0.3, beta=0.1):
+        return _one(_lib.TREND_HOLT, data, [alpha, beta], device=FinancialNoiseFilters.device)[0]
+
+
+def multi_filter_consensus(data, filters=("savgol", "kalman", "holt")):
+    """-> (nanmedian of the filter outputs, 1 / (1 + nanstd))  (financial_filters.py:256-298)."""
+    data = np.asarray(data, dtype=np.float64)
+    f = FinancialNoiseFilters
+    results = []
+    if "savgol" in filters:
+        results.append(f.savitzky_golay(data))
+    if "kalman" in filters:
+        results.append(f.kalman_filter(data))
+    if "holt" in filters:
+        results.append(f.holt_winters(data))
+    if not results:
+        return data, np.ones_like(data)
+    if len(data) == 0:
+        return data.copy(), np.ones_like(data)
+    med, conf = _handle(f.device).trend(_lib.TREND_CONSENSUS, np.array(results), [len(results)], n_out=2,
+                                        stacked_rows=len(results))
+    return med[0], conf[0]
+
+
+class FinancialPitchAnalyzer:
+    def __init__(self, sr=22050, hop_length=512, device=0):
+        self.sr = sr
+        self.hop_length = hop_length
+        self.ms_per_frame = (hop_length / sr) * 1000
+        self.device = device
+
+    def _op(self, op, data, params, n_out=1, dtype=np.float64):
+        return _one(op, data, params, n_out, dtype, self.device)
+
+    def simple_moving_average(self, data, window=5):
+        data = np.asarray(data, dtype=np.float64)
+        if len(data) < window:      # np.convolve(..., 'same') returns `window` samples and the NaN restore fails
+            raise IndexError(f"boolean index did not match indexed array along axis 0; size of axis is {window} "
+                             f"but size of corresponding boolean axis is {len(data)}")
+        return self._op(_lib.TREND_SMA, data, [window])[0]
+
+    def exponential_moving_average(self, data, span=5):
+        return self._op(_lib.TREND_EMA, data, [span])[0]
+
+    def bollinger_bands(self, data, window=20, num_std=2):
+        data = np.asarray(data, dtype=np.float64)
+        if len(data) < window:
+            raise IndexError(f"series of {len(data)} samples is shorter than the window {window}")
+        return tuple(self._op(_lib.TREND_BOLLINGER, data, [window, num_std], n_out=3))
+
+    def detect_articulation_bollinger(self, f0, window=10, sensitivity=2.0):
+        f0 = np.asarray(f0, dtype=np.float64)
+        if len(f0) < window:
+            raise IndexError(f"series of {len(f0)} samples is shorter than the window {window}")
+        codes = self._op(_lib.TREND_ARTICULATION, f0, [window, sensitivity], dtype=np.int8)[0]
+        return [_ARTICULATIONS[c] for c in codes]
+
+    def macd(self, data, fast=12, slow=26, signal=9):
+        return tuple(self._op(_lib.TREND_MACD, data, [fast, slow, signal], n_out=3))
+
+    def detect_slides_macd(self, f0, threshold=0.5):
+        codes = self._op(_lib.TREND_SLIDES, f0, [threshold], dtype=np.int8)[0]
+        return [_SLIDES[c] for c in codes]
+
+    def rsi(self, data, period=14):
+        return self._op(_lib.TREND_RSI, data, [period])[0]
+
+    def filter_ghost_notes_rsi(self, note_events, rsi_threshold=70):
+        """financial_analysis.py:322-362, including its mixed units: `start`/`end` are scaled by 10 as if
+        they were seconds whatever the caller stores there."""
+        if not note_events:
+            return note_events
+        max_time = max(e["end"] for e in note_events)
+        density = np.zeros(len(np.linspace(0, max_time, int(max_time * 10))))
+        for e in note_events:
+            a, b = int(e["start"] * 10), int(e["end"] * 10)
+            if a < len(density):
+                density[a:min(b, len(density))] += 1
+        rsi_values = self.rsi(density, period=14) if len(density) else np.zeros(0)
+        kept = []
+        for e in note_events:
+            i = int(e["start"] * 10)
+            if i >= len(rsi_values) or rsi_values[i] < rsi_threshold:
+                kept.append(e)
+        return kept
+
+    def analyze_pitch_financial(self, f0, voiced_flag, use_advanced_filters=True):
+        """-> {'trend', 'articulations', 'slides', 'confidence'}  (financial_analysis.py:368-423)."""
+        f0 = np.asarray(f0, dtype=np.float64)
+        if use_advanced_filters:
+            trend, _ = multi_filter_consensus(f0, filters=["savgol", "kalman", "holt"])
+        else:
+            trend = self.exponential_moving_average(f0, span=5)
+        articulations = self.detect_articulation_bollinger(f0, window=10)
+        slides = self.detect_slides_macd(f0, threshold=0.3)
+        _, upper, lower = self.bollinger_bands(f0, window=10)
+        width = upper - lower
+        ok = ~np.isnan(f0) & ~np.isnan(width)
+        confidence = np.zeros_like(f0)
+        confidence[ok] = np.where(width[ok] > 0, 1.0 / (1.0 + width[ok]), 1.0)
+        return {"trend": trend, "articulations": articulations, "slides": slides, "confidence": confidence}

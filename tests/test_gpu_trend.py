@@ -1,0 +1,118 @@
+"""v2 trend filters on the GPU (aegis_trend) against goldens produced by the
+reference's own financial_analysis.py / financial_filters.py -- PINNED.  Sequential recurrences (EMA, MACD,
+RSI, Kalman, Holt) and the state machines are expected bit-exact; windowed sums within 1e-12 relative (the
+reference's np.convolve / BLAS summation order is not specified)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from spectrogram_midi_amd import _lib
+from spectrogram_midi_amd.financial import FinancialNoiseFilters, FinancialPitchAnalyzer, multi_filter_consensus
+
+pytestmark = pytest.mark.gpu
+G = np.load(os.path.join(os.path.dirname(__file__), "golden", "v2_trend_golden.npz"))
+NAMES = [str(n) for n in G["names"]]
+ART = (None, "normal", "bend", "vibrato", "noise")
+SLD = (None, "normal", "slide_up", "slide_down")
+an = FinancialPitchAnalyzer(sr=22050, hop_length=512)
+
+
+def close(a, b, tag, rtol=1e-12, atol=1e-12):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol, equal_nan=True, err_msg=tag)
+
+
+def exact(a, b, tag):
+    np.testing.assert_array_equal(a, b, err_msg=tag)      # NaNs compare equal position-wise
+
+
+def test_moving_averages():
+    for n in NAMES:
+        x = G[f"{n}/x"]
+        for w in (5, 10, 20):
+            if f"{n}/sma{w}" in G:
+                close(an.simple_moving_average(x, window=w), G[f"{n}/sma{w}"], f"{n} sma{w}")
+            else:
+                with pytest.raises(IndexError):
+                    an.simple_moving_average(x, window=w)
+        for span in (5, 12, 26):
+            exact(an.exponential_moving_average(x, span=span), G[f"{n}/ema{span}"], f"{n} ema{span}")
+
+
+def test_bollinger_and_articulations():
+    for n in NAMES:
+        x = G[f"{n}/x"]
+        for w, k in ((10, 2.0), (20, 2)):
+            if f"{n}/boll{w}_ma" not in G:
+                continue
+            ma, up, lo = an.bollinger_bands(x, window=w, num_std=k)
+            close(ma, G[f"{n}/boll{w}_ma"], f"{n} ma{w}")
+            close(up, G[f"{n}/boll{w}_up"], f"{n} up{w}")
+            close(lo, G[f"{n}/boll{w}_lo"], f"{n} lo{w}")
+        if f"{n}/artic" in G:
+            got = an.detect_articulation_bollinger(x, window=10, sensitivity=2.0)
+            assert got == [ART[c] for c in G[f"{n}/artic"]], n
+
+
+def test_macd_slides_rsi():
+    for n in NAMES:
+        x = G[f"{n}/x"]
+        m, s, h = an.macd(x, fast=12, slow=26, signal=9)
+        exact(m, G[f"{n}/macd"], f"{n} macd"); exact(s, G[f"{n}/macd_sig"], f"{n} sig"); exact(h, G[f"{n}/macd_hist"], f"{n} hist")
+        for thr in (0.5, 0.3):
+            if f"{n}/slides{thr}" in G:
+                assert an.detect_slides_macd(x, threshold=thr) == [SLD[c] for c in G[f"{n}/slides{thr}"]], (n, thr)
+        xr = np.nan_to_num(x) if n.startswith("density") else np.nan_to_num(x) / 100.0
+        for per in (14, 5):
+            exact(an.rsi(xr, period=per), G[f"{n}/rsi{per}"], f"{n} rsi{per}")
+
+
+def test_noise_filters_and_consensus():
+    for n in NAMES:
+        x = G[f"{n}/x"]
+        close(FinancialNoiseFilters.savitzky_golay(x), G[f"{n}/savgol"], f"{n} savgol")
+        exact(FinancialNoiseFilters.kalman_filter(x), G[f"{n}/kalman"], f"{n} kalman")
+        exact(FinancialNoiseFilters.holt_winters(x), G[f"{n}/holt"], f"{n} holt")
+        med, conf = multi_filter_consensus(x)
+        close(med, G[f"{n}/cons_med"], f"{n} median")
+        close(conf, G[f"{n}/cons_conf"], f"{n} conf", rtol=1e-9)
+
+
+def test_analyze_pitch_financial():
+    for n in NAMES:
+        if f"{n}/apf_adv_trend" not in G:
+            continue
+        x = G[f"{n}/x"]
+        for adv, tag in ((True, "adv"), (False, "ema")):
+            r = an.analyze_pitch_financial(x, ~np.isnan(x), use_advanced_filters=adv)
+            close(r["trend"], G[f"{n}/apf_{tag}_trend"], f"{n} trend {tag}")
+            assert r["articulations"] == [ART[c] for c in G[f"{n}/apf_{tag}_artic"]]
+            assert r["slides"] == [SLD[c] for c in G[f"{n}/apf_{tag}_slides"]]
+            close(r["confidence"], G[f"{n}/apf_{tag}_conf"], f"{n} conf {tag}", rtol=1e-9)
+
+
+def test_ghost_note_filter_matches_reference():
+    cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "v2_harmonic_golden.json")))
+    for c in cases:
+        if not c["midi"]:
+            continue
+        events = [{"start": float(t) / 1000, "end": float(t + d) / 1000, "note": int(n)}
+                  for n, t, d in zip(c["midi"], c["times"], c["durs"])]
+        kept = an.filter_ghost_notes_rsi(events, rsi_threshold=70)
+        assert [events.index(e) for e in kept] == c["ghost_kept"], c["name"]
+    assert an.filter_ghost_notes_rsi([]) == []
+
+
+def test_ragged_batch_equals_single_series():
+    h = _lib.Handle(scipy_tables=False)
+    series = [G[f"{n}/x"] for n in NAMES if len(G[f"{n}/x"]) >= 26]
+    batch = h.trend(_lib.TREND_EMA, series, [12])[0]
+    for s, b in zip(series, batch):
+        exact(b, an.exponential_moving_average(s, span=12), "batch ema")
+    k = h.trend(_lib.TREND_KALMAN, series, [1e-5, 1e-1])[0]
+    for s, b in zip(series, k):
+        exact(b, FinancialNoiseFilters.kalman_filter(s), "batch kalman")
+    with pytest.raises(_lib.AegisError):
+        h.trend(99, series, [1])
+    h.close()
