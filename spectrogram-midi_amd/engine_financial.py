@@ -1,0 +1,89 @@
+"""`AegisFinancialEngine`: the reference's v2 engine facade (/root/reference/aegis_engine_financial.py:23-253,
+default rate 22 050 Hz) over the MI355X kernels: load -> mel/dB -> rake -> pYIN -> guitar filters -> RMS ->
+financial event extraction -> two-track SMF.  Same constructor, methods, kwargs and return values."""
+import struct
+
+import numpy as np
+
+from . import _lib, audio_io
+from .convert import note_to_hz
+from .guitar import apply_guitar_filters
+from .midi_logic_financial import get_midi_events_financial
+from .smf import Track
+
+
+class AegisFinancialEngine:
+    def __init__(self, sample_rate=22050, hop_length=512, n_fft=2048, device=0, verbose=False):
+        self.sr = sample_rate
+        self.hop_length = hop_length
+        self.n_fft = n_fft
+        self.version = "2.0-Financial"
+        self.device = device
+        self.verbose = verbose
+        self._handle = None
+
+    @property
+    def handle(self):
+        if self._handle is None:
+            self._handle = _lib.Handle(sample_rate=self.sr, hop_length=self.hop_length, n_fft=self.n_fft,
+                                       fmin=note_to_hz("E2"), fmax=note_to_hz("C6"), device=self.device)
+        return self._handle
+
+    def load_audio(self, file_path, start_time=0, end_time=None):
+        duration = (end_time - start_time) if end_time else None
+        y = audio_io.read_wav(file_path, self.sr, offset=start_time, duration=duration)
+        return y, self.handle.analyze_batch([y], stages=_lib.STAGE_MEL)[0]["S_dB"]
+
+    def detect_rake_patterns(self, S_dB, rake_sensitivity=0.6):
+        return self.handle.rake_patterns(S_dB, rake_sensitivity)
+
+    def pitch_tracking(self, y):
+        r = self.handle.analyze_batch([np.asarray(y, np.float32)], stages=_lib.STAGE_PYIN)[0]
+        return r["f0"], r["voiced_flag"], r["voiced_prob"]
+
+    def analyze_array(self, y, **kwargs):
+        """Everything of audio_to_midi_financial up to the event list, from decoded PCM (one GPU call)."""
+        y = np.ascontiguousarray(y, dtype=np.float32)
+        r = self.handle.analyze_batch([y], rake_sensitivity=kwargs.get("rake_sensitivity", 0.6))[0]
+        f0, voiced, rake = r["f0"], r["voiced_flag"], r["rake_mask"]
+        if kwargs.get("use_guitar_filters", True):
+            g = apply_guitar_filters(f0, voiced, r["S_dB"], self.hop_length, self.sr, rake)
+            f0, rake = g["f0"], g["rake_mask"]
+            voiced = g["voiced"] & ~g["mute_mask"]
+        passthrough = {k: v for k, v in kwargs.items()
+                       if k not in ("confidence_threshold", "rake_sensitivity", "use_financial")}
+        return get_midi_events_financial(
+            rake_mask=rake, f0=f0, voiced_flag=voiced, active_probs=r["voiced_prob"], rms=r["rms"], sr=self.sr,
+            hop_length=self.hop_length, confidence_threshold=kwargs.get("confidence_threshold", None),
+            use_financial=kwargs.get("use_financial", True), verbose=self.verbose, **passthrough)
+
+    def render_midi(self, events):
+        """aegis_engine_financial.py:190-245: track_name metas, note_on at the start tick, note_off after
+        the duration, per-track running clock (type 1, 480 ticks per beat, 120 BPM tick length)."""
+        ms_per_tick = 500 / 480
+        ms_per_frame = (self.hop_length / self.sr) * 1000
+        tracks = {"main": Track(), "safe": Track()}
+        blobs = {}
+        for name, label in (("main", b"Aegis Financial - Main"), ("safe", b"Aegis Financial - Safe")):
+            blobs[name] = b"\x00\xff\x03" + bytes([len(label)]) + label
+        for e in events:
+            t = tracks["main" if e["track"] == "main" else "safe"]
+            start = int(e["start"] * ms_per_frame / ms_per_tick)
+            length = int((e["end"] - e["start"]) * ms_per_frame / ms_per_tick)
+            t.note_on(start, e["note"], e["velocity"])
+            t.note_off(start + length, e["note"], 0)
+        out = b"MThd" + struct.pack(">IHHH", 6, 1, 2, 480)
+        for name in ("main", "safe"):
+            body = blobs[name] + bytes(tracks[name]._data) + b"\x00\xff\x2f\x00"
+            out += b"MTrk" + struct.pack(">I", len(body)) + body
+        return out
+
+    def audio_to_midi_financial(self, input_wav, output_mid, **kwargs):
+        """-> output_mid, or None when no note was found (aegis_engine_financial.py:73-253)."""
+        y = audio_io.read_wav(input_wav, self.sr)
+        events = self.analyze_array(y, **kwargs)
+        if not events:
+            return None
+        with open(output_mid, "wb") as f:
+            f.write(self.render_midi(events))
+        return output_mid
