@@ -759,6 +759,7 @@ __device__ __forceinline__ double read_lane_f64(double v, int l) {
 template <int H>
 struct BandLT {
     double v[4][2 * H + 1];   // [v*2+v'][dd]
+    double lmax[4];           // [v*2+v'] largest log-transition of that block over ALL row classes
 };
 
 template <int H, bool LT_LDS>
@@ -771,14 +772,17 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int PADB = (B + 2 * H + 64 + 7) & ~7;            // slack: inactive lanes read past B+2H
     double *valI = reinterpret_cast<double *>(smem_raw);   // [2 buf][2 v][PADB], index b + H
     double *valE = valI + 4 * PADB;                        // [2 buf][2 v][2H]
-    double *rv = valE + 8 * H;                             // [2][16]
-    int *ri = reinterpret_cast<int *>(rv + 32);            // [2][16]
+    double *rv = valE + 8 * H;                             // [2][16]  wave maxima
+    double *rvU = rv + 32;                                 // [2][16]  wave maxima over unobserved voiced states
+    unsigned long long *omask = reinterpret_cast<unsigned long long *>(rvU + 32);   // [2][16] observed-state ballots of the voiced waves
+    int *ri = reinterpret_cast<int *>(omask + 32);         // [2][16]
     uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [C][S]
     double *ltl = reinterpret_cast<double *>(
-        smem_raw + (((size_t)(4 * PADB + 8 * H + 32) * 8 + 32 * 4 + (size_t)C * S * 2 + 15) / 16) * 16);
+        smem_raw + (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)C * S * 2 + 15) / 16) * 16);
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
     const int vp = __builtin_amdgcn_readfirstlane(tid >= BP ? 1 : 0);
+    const int nvw = BP >> 6;                      // voiced waves are [0, nvw)
     const int b2 = tid - vp * BP;
     const bool act = b2 < B;
     const int b2c = act ? b2 : 0;
@@ -790,18 +794,19 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int eidx = is_low ? b2c : b2c - B + 2 * H;
 
     for (int i = tid; i < 4 * PADB + 8 * H; i += nthr) valI[i] = -INFINITY;
-    // edge-row table: LDS copy of the band table; the (unused here) interior row of each
-    // (v,v') block donates its first slot as a -inf sentinel for out-of-reach (lane, source) pairs
+    // LDS copy of the band table (edge rows + list lookups).  Slot [class 0][dd = 0] of every (v,v')
+    // block is never a real transition (it would be a target bin of -H): it holds the -inf sentinel
+    // that out-of-reach (lane, source) pairs are redirected to.
     const double *lt_e0;   // block (v = 0, v' = vp); the v = 1 block sits 2*NC*W further
     if (LT_LDS) {
-        for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = (i % (NC * W) == H * W) ? -INFINITY : tb.lt_band[i];
+        for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = (i % (NC * W) == 0) ? -INFINITY : tb.lt_band[i];
         lt_e0 = ltl + (size_t)vp * NC * W;
     } else {
         lt_e0 = tb.lt_band + (size_t)vp * NC * W;
     }
     const double *lti0 = blt.v[0 * 2 + vp];   // interior row, source v = 0, target v' = vp
     const double *lti1 = blt.v[1 * 2 + vp];   // source v = 1
-    constexpr int kSentinel = H * W;
+    constexpr int kSentinel = 0;
 
     const int c = p.order[blockIdx.x];
     const int64_t f0 = p.frame_off[c];
@@ -827,58 +832,66 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     if (p.vt_begin >= T && p.vt_begin != 0) return;             // clip finished in an earlier launch
     double *__restrict__ vst = p.vstate + (int64_t)c * S;
     double myv = -INFINITY;
+    bool observed = false;        // voiced state whose observation at the column's frame is not log(tiny)
     if (act) {
-        if (p.vt_begin == 0) {
-            const double lp = vp ? lunv[0] : lobs[b2c];
-            myv = lp + p.log_pinit;
-        } else {
-            myv = vst[j];
-        }
+        const int tprev = p.vt_begin == 0 ? 0 : t_lo - 1;
+        const double lp = vp ? lunv[tprev] : lobs[(int64_t)tprev * os + b2c];
+        myv = p.vt_begin == 0 ? lp + p.log_pinit : vst[j];
+        observed = !vp && lp != p.log_tiny;
         store_value(0, myv);
     }
     int par = 0;
-    double G;
+    double G, MU;     // column max (all states); max over the voiced states without an observation
     int kg;
-    // block arg-max (lowest index on ties): DPP wave max -> first lane holding it -> one LDS slot
-    // per wave -> every wave reduces the <=16 slots the same way.  Waves and lanes are in state order.
-    auto block_argmax = [&](double v) {
+    // End-of-step bookkeeping, one barrier: block arg-max (lowest index on ties; DPP wave max -> first
+    // lane holding it -> one LDS slot per wave -> every wave reduces the <= 16 slots), the max over
+    // the unobserved voiced states, and one ballot mask per voiced wave marking the observed voiced states.
+    auto end_of_step = [&](double v, bool obs) {
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 2)
-        __syncthreads(); G = v; kg = 0; return;
+        __syncthreads(); G = v; kg = 0; MU = INFINITY; return;
 #endif
         double m = row16_prefix_max(v);
         m = dpp_fmax<0x142, 0xa>(m);   // row_bcast:15
         m = dpp_fmax<0x143, 0xc>(m);   // row_bcast:31
         const double wm = read_lane_f64(m, 63);
         const unsigned long long eq = __ballot(v == wm);
+        if (!vp) {                     // wave-uniform
+            double u = row16_prefix_max((act && !obs) ? v : -INFINITY);
+            u = dpp_fmax<0x142, 0xa>(u);
+            u = dpp_fmax<0x143, 0xc>(u);
+            const unsigned long long om = __ballot(obs);
+            if (lane == 63) rvU[par * 16 + wid] = u;
+            if (lane == 0) omask[par * 16 + wid] = om;
+        }
         if (lane == 0) {
             rv[par * 16 + wid] = wm;
             ri[par * 16 + wid] = eq ? vp * B + wlo + (int)__ffsll((long long)eq) - 1 : 0x7fffffff;
         }
         __syncthreads();
-        double a = -INFINITY;
+        double a = -INFINITY, au = -INFINITY;
         int ai = 0x7fffffff;
         if (lane < nw) { a = rv[par * 16 + lane]; ai = ri[par * 16 + lane]; }
+        if (lane < nvw) au = rvU[par * 16 + lane];
         const double pm = row16_prefix_max(a);
         G = read_lane_f64(pm, 15);
+        MU = read_lane_f64(row16_prefix_max(au), 15);
         const unsigned long long eq2 = __ballot(a == G) & 0xffffull;
         kg = __builtin_amdgcn_readlane(ai, eq2 ? (int)__ffsll((long long)eq2) - 1 : 0);
         par ^= 1;
     };
-    block_argmax(myv);
+    end_of_step(myv, observed);
 
     int cur = 0;
     for (int t = t_lo; t < t_hi; ++t) {
         double lp = 0.0;
         if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
+        const int lpar = par ^ 1;      // parity the previous end_of_step wrote its lists under
 
         const double *vi0 = valI + (cur * 2 + 0) * PADB + b2c;
         const double *vi1 = valI + (cur * 2 + 1) * PADB + b2c;
         const double *ve0 = valE + (cur * 2 + 0) * 2 * H;
         const double *ve1 = valE + (cur * 2 + 1) * 2 * H;
         const double *lt_e1 = lt_e0 + (size_t)2 * NC * W;
-        // two independent compare chains (voiced sources, unvoiced sources), each in state-index
-        // order: low-edge rows, interior rows, high-edge rows; merged in index order at the end.
-        // code: [0,64) low-edge source e, [64,192) interior offset d, [192,..) high-edge source.
         // edge sources: table offset of (source e, this lane) = lane base + e*(W-1); pairs out of
         // reach are redirected to the -inf sentinel (LDS copy) or predicated (global table).
         // The opaque copy of b' keeps these cheap per-step integer ops from being hoisted out of
@@ -890,59 +903,136 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         const int reach_lo = act ? bl - H : 0x7fffffff;           // low source e in reach  <=> e >= reach_lo
         const int reach_hi = act ? bl - (B - 2 * H) : -1;         // high source e in reach <=> e <= reach_hi
 
-        // interior-row sources: two independent compare chains (voiced / unvoiced sources)
-        double best = -INFINITY, best1 = -INFINITY;
-        int code = 0, code1 = 0;
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 4)
-        best = vi0[H] + lti0[H]; best1 = vi1[H] + lti1[H];
-#else
+        // ---- unvoiced sources (v = 1): always the full band, two interleaved half chains ----------
+        double best1 = -INFINITY, best1b = -INFINITY;
+        int code1 = 0, code1b = 0;
+        constexpr int HALF = (W + 1) / 2;
 #pragma unroll
-        for (int d = 0; d < W; ++d) {
-            const double cand = vi0[d] + lti0[W - 1 - d];
-            if (cand > best) code = d;
-            best = fmax(best, cand);
-            const double cand1 = vi1[d] + lti1[W - 1 - d];
-            if (cand1 > best1) code1 = d;
-            best1 = fmax(best1, cand1);
+        for (int d = 0; d < HALF; ++d) {
+            const double cand = vi1[d] + lti1[W - 1 - d];
+            if (cand > best1) code1 = d;
+            best1 = fmax(best1, cand);
+            if (HALF + d < W) {
+                const double candb = vi1[HALF + d] + lti1[W - 1 - HALF - d];
+                if (candb > best1b) code1b = HALF + d;
+                best1b = fmax(best1b, candb);
+            }
         }
-#endif
-        int src = b2c + code - H, src1 = b2c + code1 - H;    // source bins of the two chains
+        if (best1b > best1) { best1 = best1b; code1 = code1b; }
+        int src1 = b2c + code1 - H;
 #if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
         if (wave_low) {     // low-edge sources precede the interior ones in state order: they win ties
-            double eb = -INFINITY, eb1 = -INFINITY;
-            int ec = 0, ec1 = 0;
+            double eb1 = -INFINITY;
+            int ec1 = 0;
 #pragma unroll
             for (int e = 0; e < H; ++e) {
                 const bool ok = e >= reach_lo;
                 const int off = (LT_LDS && !ok) ? kSentinel : ebase_lo + e * (W - 1);
-                const double cand = (LT_LDS || ok) ? ve0[e] + lt_e0[off] : -INFINITY;
-                if (cand > eb) ec = e;
-                eb = fmax(eb, cand);
                 const double cand1 = (LT_LDS || ok) ? ve1[e] + lt_e1[off] : -INFINITY;
                 if (cand1 > eb1) ec1 = e;
                 eb1 = fmax(eb1, cand1);
             }
-            if (eb >= best) { best = eb; src = ec; }
             if (eb1 >= best1) { best1 = eb1; src1 = ec1; }
         }
         if (wave_high) {    // high-edge sources follow the interior ones: they lose ties
-            double eb = -INFINITY, eb1 = -INFINITY;
-            int ec = 0, ec1 = 0;
+            double eb1 = -INFINITY;
+            int ec1 = 0;
 #pragma unroll
             for (int e = 0; e < H; ++e) {
                 const bool ok = e <= reach_hi;
                 const int off = (LT_LDS && !ok) ? kSentinel : ebase_hi + e * (W - 1);
-                const double cand = (LT_LDS || ok) ? ve0[H + e] + lt_e0[off] : -INFINITY;
-                if (cand > eb) ec = e;
-                eb = fmax(eb, cand);
                 const double cand1 = (LT_LDS || ok) ? ve1[H + e] + lt_e1[off] : -INFINITY;
                 if (cand1 > eb1) ec1 = e;
                 eb1 = fmax(eb1, cand1);
             }
-            if (eb > best) { best = eb; src = B - H + ec; }
             if (eb1 > best1) { best1 = eb1; src1 = B - H + ec1; }
         }
 #endif
+
+        // ---- voiced sources (v = 0) ------------------------------------------------------------------
+        // Exact pruning.  Voiced states whose previous-frame observation was log(tiny) carry that -708
+        // in their value.  No candidate built on one of them can exceed MU + lmax (MU = their column
+        // max, lmax = largest log-transition of the block; rounding is monotone).  If that bound is
+        // strictly below the unvoiced chain's result in every lane of the wave, such sources can neither
+        // win nor tie anywhere in the wave, and only the observed voiced states -- a handful per frame,
+        // listed in ascending bin order by the previous step -- remain to be examined.
+        double best = -INFINITY;
+        int src = 0;
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 8)
+        const bool list_only = true;
+#elif defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 16)
+        const bool list_only = false;
+#else
+        const bool list_only = LT_LDS && __all(!act || (MU + blt.lmax[0 * 2 + vp] < best1));
+#endif
+        if (list_only) {
+            // observed bins within reach of this wave's targets: [wlo - H, whi + H] spans <= 3 mask words
+            const int rlo = max(wlo - H, 0), rhi = min(whi + H, B - 1);
+            for (int w = rlo >> 6; w <= (rhi >> 6); ++w) {
+                unsigned long long m = omask[lpar * 16 + w];
+                if (w == (rlo >> 6)) m &= ~0ull << (rlo & 63);
+                if (w == (rhi >> 6)) m &= ~0ull >> (63 - (rhi & 63));
+                m = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                    (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+                while (m) {                                  // ascending bins: strict '>' keeps the lowest index
+                    const int bo = (w << 6) + (int)__ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const bool lo_e = bo < H, hi_e = bo > B - 1 - H;
+                    const double vo = (lo_e || hi_e) ? ve0[lo_e ? bo : bo - B + 2 * H] : valI[(cur * 2 + 0) * PADB + bo + H];
+                    const int cl = lo_e ? bo : (hi_e ? bo - (B - 1 - 2 * H) : H);
+                    const int dd = b2c - bo + H;
+                    const int off = (act && (unsigned)dd < (unsigned)W) ? cl * W + dd : kSentinel;
+                    const double cand = vo + lt_e0[off];
+                    if (cand > best) src = bo;
+                    best = fmax(best, cand);
+                }
+            }
+        } else {
+            double besta = -INFINITY, bestb = -INFINITY;
+            int codea = 0, codeb = 0;
+#pragma unroll
+            for (int d = 0; d < HALF; ++d) {
+                const double cand = vi0[d] + lti0[W - 1 - d];
+                if (cand > besta) codea = d;
+                besta = fmax(besta, cand);
+                if (HALF + d < W) {
+                    const double candb = vi0[HALF + d] + lti0[W - 1 - HALF - d];
+                    if (candb > bestb) codeb = HALF + d;
+                    bestb = fmax(bestb, candb);
+                }
+            }
+            if (bestb > besta) { besta = bestb; codea = codeb; }
+            best = besta;
+            src = b2c + codea - H;
+#if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
+            if (wave_low) {
+                double eb = -INFINITY;
+                int ec = 0;
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    const bool ok = e >= reach_lo;
+                    const int off = (LT_LDS && !ok) ? kSentinel : ebase_lo + e * (W - 1);
+                    const double cand = (LT_LDS || ok) ? ve0[e] + lt_e0[off] : -INFINITY;
+                    if (cand > eb) ec = e;
+                    eb = fmax(eb, cand);
+                }
+                if (eb >= best) { best = eb; src = ec; }
+            }
+            if (wave_high) {
+                double eb = -INFINITY;
+                int ec = 0;
+#pragma unroll
+                for (int e = 0; e < H; ++e) {
+                    const bool ok = e <= reach_hi;
+                    const int off = (LT_LDS && !ok) ? kSentinel : ebase_hi + e * (W - 1);
+                    const double cand = (LT_LDS || ok) ? ve0[H + e] + lt_e0[off] : -INFINITY;
+                    if (cand > eb) ec = e;
+                    eb = fmax(eb, cand);
+                }
+                if (eb > best) { best = eb; src = B - H + ec; }
+            }
+#endif
+        }
         int bi = src;
         if (best1 > best) { best = best1; bi = B + src1; }
         // the one out-of-band candidate that can win: the previous column's arg-max
@@ -955,13 +1045,15 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             }
         }
         myv = -INFINITY;
+        observed = false;
         if (act) {
             myv = lp + best;
+            observed = !vp && lp != p.log_tiny;
             store_value(cur ^ 1, myv);
             ring[((t - 1) % C) * S + j] = (uint16_t)bi;
             ptr[(int64_t)t * S + j] = (uint16_t)bi;
         }
-        block_argmax(myv);
+        end_of_step(myv, observed);
         cur ^= 1;
         if (t % C == 0 || t == T - 1) {
             const int cc = (t - 1) / C;
@@ -997,7 +1089,7 @@ template <int H>
 static size_t viterbi_band_lds(const PassParams &p, bool lt_lds) {
     const int B = p.n_bins, S = 2 * B;
     const int PADB = (B + 2 * H + 64 + 7) & ~7;
-    size_t b = (((size_t)(4 * PADB + 8 * H + 32) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16) * 16;
+    size_t b = (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16) * 16;
     if (lt_lds) b += (size_t)4 * p.n_cls * (2 * H + 1) * 8;
     return b;
 }
@@ -1188,16 +1280,22 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
         // band-specialised kernels for the two hop/sr ratios the reference uses (44.1k and 22.05k at hop 512)
         if (p.half_width == 25 && viterbi_band_lds<25>(p, true) <= 160 * 1024) {
             BandLT<25> blt;
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
                 std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 25) * p.width, sizeof(blt.v[q]));
+                blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width,
+                                                host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
+            }
             hipLaunchKernelGGL((viterbi_band_kernel<25, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
                                viterbi_band_lds<25>(p, true), s, p, t, blt);
             return hipGetLastError();
         }
         if (p.half_width == 50 && viterbi_band_lds<50>(p, false) <= 160 * 1024) {
             BandLT<50> blt;
-            for (int q = 0; q < 4; ++q)
+            for (int q = 0; q < 4; ++q) {
                 std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 50) * p.width, sizeof(blt.v[q]));
+                blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width,
+                                                host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
+            }
             hipLaunchKernelGGL((viterbi_band_kernel<50, false>), dim3((unsigned)p.n_clips), dim3(2 * BP),
                                viterbi_band_lds<50>(p, false), s, p, t, blt);
             return hipGetLastError();
