@@ -104,6 +104,24 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
 int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int64_t n_frames,
                         double broadband_threshold_ratio, uint8_t *mask_out);
 
+/* --- incremental analysis of one clip (BASELINE.json configs[4]; the reference has no streaming path:
+ * financial_app_realtime.py analyses whole files).  Samples are pushed in any chunk sizes; every frame whose
+ * centred 2048-sample window is complete is analysed at once (mel, YIN, observation) and the Viterbi advances
+ * over it, its column carried exactly between pushes.  aegis_stream_push returns, for the frames it produced,
+ * the final rms and voiced_prob plus a zero-lag decode (arg-max state of the current column: `live_state`,
+ * < n_pitch_bins = voiced bin, otherwise unvoiced).  aegis_stream_close zero-pads the tail exactly as the
+ * batch path does, back-traces, and returns arrays IDENTICAL to aegis_analyze_batch on the whole signal. */
+typedef struct aegis_stream aegis_stream;
+typedef struct aegis_stream_frames {
+    float *rms;           /* [>= frames produced by the push] host arrays, any may be NULL */
+    double *voiced_prob;
+    int32_t *live_state;
+} aegis_stream_frames;
+int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out);
+int aegis_stream_push(aegis_stream *st, const float *samples, int64_t n, aegis_stream_frames *out, int64_t *n_frames);
+int aegis_stream_close(aegis_stream *st, double rake_sensitivity, aegis_outputs *host_out, int64_t *n_frames);
+void aegis_stream_free(aegis_stream *st);
+
 /* --- v2 "financial" trend filters on pitch tracks -------------------
  * One op-coded entry over a ragged batch of float64 series in host memory: series i is
  * x[offsets[i] .. offsets[i+1]) (NaN = unvoiced); outputs are host arrays of offsets[n_series]

@@ -26,6 +26,10 @@ class Config(C.Structure):
                 ("device", C.c_int32), ("reserved", C.c_int32), ("max_frames_per_pass", C.c_int64)]
 
 
+class StreamFrames(C.Structure):
+    _fields_ = [("rms", C.c_void_p), ("voiced_prob", C.c_void_p), ("live_state", C.c_void_p)]
+
+
 class Outputs(C.Structure):
     _fields_ = [("f0", C.c_void_p), ("voiced_flag", C.c_void_p), ("voiced_prob", C.c_void_p),
                 ("rms", C.c_void_p), ("rake_mask", C.c_void_p), ("S_dB", C.c_void_p)]
@@ -33,7 +37,8 @@ class Outputs(C.Structure):
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
-           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend")
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend",
+           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free")
 
 _lib = None
 
@@ -68,6 +73,14 @@ def load():
     lib.aegis_trend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(C.c_void_p), C.c_int32]
     lib.aegis_trend.restype = C.c_int
+    lib.aegis_stream_open.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.aegis_stream_open.restype = C.c_int
+    lib.aegis_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(StreamFrames), C.POINTER(C.c_int64)]
+    lib.aegis_stream_push.restype = C.c_int
+    lib.aegis_stream_close.argtypes = [C.c_void_p, C.c_double, C.POINTER(Outputs), C.POINTER(C.c_int64)]
+    lib.aegis_stream_close.restype = C.c_int
+    lib.aegis_stream_free.argtypes = [C.c_void_p]
+    lib.aegis_stream_free.restype = None
     lib.aegis_set_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_set_table.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -245,6 +258,9 @@ class Handle:
                                          par.ctypes.data, len(par), ptrs, n_out))
         return [[o[off[i]:off[i + 1]] for i in range(len(lens))] for o in outs]
 
+    def open_stream(self, max_seconds=600.0):
+        return Stream(self, int(max_seconds * self.sr))
+
     def analyze_batch_device(self, d_pcm_ptr, sample_offsets, outputs, rake_sensitivity=0.6,
                              stages=STAGE_ALL, stream=None, sync=True):
         """PCM and outputs already in device memory (raw pointers as ints).  `outputs` maps the
@@ -256,3 +272,59 @@ class Handle:
         self._check(self.lib.aegis_analyze_batch_device(
             self._h, C.c_void_p(int(d_pcm_ptr)), off.ctypes.data_as(C.POINTER(C.c_int64)), len(off) - 1,
             float(rake_sensitivity), int(stages), C.byref(out), C.c_void_p(stream or 0), 1 if sync else 0))
+
+
+class Stream:
+    """Incremental analysis of one clip (aegis_stream_*).  push() returns the frames that became complete:
+    dict(rms, voiced_prob, live_state); close() returns the same dict analyze_batch() gives for the whole
+    signal (bit-identical)."""
+
+    def __init__(self, handle, max_samples):
+        self.handle = handle
+        self.lib = handle.lib
+        s = C.c_void_p()
+        handle._check(self.lib.aegis_stream_open(handle._h, int(max_samples), C.byref(s)))
+        self._s = s
+        self._cap = 8 + max_samples // handle.hop
+        self._rms = np.empty(self._cap, np.float32)
+        self._vp = np.empty(self._cap, np.float64)
+        self._live = np.empty(self._cap, np.int32)
+        self._frames = StreamFrames(self._rms.ctypes.data, self._vp.ctypes.data, self._live.ctypes.data)
+        self.n_bins = handle.param("n_pitch_bins")
+
+    def push(self, samples):
+        x = np.ascontiguousarray(samples, dtype=np.float32)
+        k = C.c_int64(0)
+        self.handle._check(self.lib.aegis_stream_push(self._s, x.ctypes.data, len(x), C.byref(self._frames), C.byref(k)))
+        n = k.value
+        return {"rms": self._rms[:n].copy(), "voiced_prob": self._vp[:n].copy(), "live_state": self._live[:n].copy()}
+
+    def close(self, rake_sensitivity=0.6, want_sdb=True):
+        h = self.handle
+        cap = self._cap
+        bufs = {"f0": np.empty(cap, np.float64), "voiced_flag": np.empty(cap, np.uint8), "voiced_prob": np.empty(cap, np.float64),
+                "rms": np.empty(cap, np.float32), "rake_mask": np.empty(cap, np.uint8)}
+        if want_sdb:
+            bufs["S_dB"] = np.empty(cap * h.n_mels, np.float32)
+        out = Outputs()
+        for k, v in bufs.items():
+            setattr(out, k, v.ctypes.data)
+        F = C.c_int64(0)
+        h._check(self.lib.aegis_stream_close(self._s, float(rake_sensitivity), C.byref(out), C.byref(F)))
+        F = F.value
+        res = {}
+        for k, v in bufs.items():
+            if k == "S_dB":
+                res[k] = v[:F * h.n_mels].reshape(h.n_mels, F).copy()
+            elif k in ("voiced_flag", "rake_mask"):
+                res[k] = v[:F].astype(bool)
+            else:
+                res[k] = v[:F].copy()
+        return res
+
+    def free(self):
+        if getattr(self, "_s", None):
+            self.lib.aegis_stream_free(self._s)
+            self._s = None
+
+    __del__ = free

@@ -64,6 +64,21 @@ struct aegis_handle {
     std::mutex mu;                            // one analyze call at a time per handle (server.py shares an engine)
 };
 
+// One clip fed incrementally (aegis_stream_*): its own PCM buffer and workspace, so batch calls on
+// the same handle may interleave.  Frames are analysed as soon as their 2048-sample window is
+// complete; the Viterbi column is carried across pushes exactly as the offline pipeline carries it
+// across time chunks, so aegis_stream_close() returns what aegis_analyze_batch() returns.
+struct aegis_stream {
+    aegis_handle *h = nullptr;
+    int64_t cap_samples = 0, cap_frames = 0;
+    int64_t n_samples = 0;      // samples received
+    int64_t frames_done = 0;    // frames analysed (= Viterbi columns produced)
+    bool closed = false;
+    DevBuf pcm, acf, yin, logobs, logunv, ptr, cmap, bnd, states, live, melpow, clipmax, rake_raw, vstate, meta;
+    DevBuf o_f0, o_voiced, o_vprob, o_rms, o_rake, o_sdb;
+    std::vector<int64_t> host_meta;
+};
+
 namespace {
 
 #define HIPCHK(h, expr)                                                                         \
@@ -102,6 +117,15 @@ int upload_table(aegis_handle *h, const std::vector<T> &v, const T **dst) {
     if (!v.empty()) HIPCHK(h, hipMemcpy(d, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     *dst = static_cast<const T *>(d);
     return AEGIS_OK;
+}
+
+PassParams base_params(const Tables &t) {
+    PassParams p{};
+    p.sr = t.sr; p.hop = t.hop; p.n_mels = t.n_mels;
+    p.min_period = t.min_period; p.max_period = t.max_period; p.n_lags = t.n_lags;
+    p.n_bins = t.n_bins; p.half_width = t.half_width; p.width = t.width; p.n_cls = t.n_cls;
+    p.fmin = t.fmin; p.log_tiny = t.log_tiny; p.log_pinit = t.log_pinit;
+    return p;
 }
 
 void free_buf(DevBuf &b) {
@@ -340,11 +364,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipMemcpyAsync(h->order.p, m.order.data(), nc * 4, hipMemcpyHostToDevice, s));
         if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(h->clipmax.p, 0, nc * 4, s));
 
-        PassParams p{};
-        p.sr = t.sr; p.hop = t.hop; p.n_mels = t.n_mels;
-        p.min_period = t.min_period; p.max_period = t.max_period; p.n_lags = t.n_lags;
-        p.n_bins = t.n_bins; p.half_width = t.half_width; p.width = t.width; p.n_cls = t.n_cls;
-        p.fmin = t.fmin; p.log_tiny = t.log_tiny; p.log_pinit = t.log_pinit;
+        PassParams p = base_params(t);
         p.stages = stages;
         p.pcm = d_pcm;
         p.sample_off = static_cast<const int64_t *>(h->sample_off.p);
@@ -518,6 +538,176 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
                         static_cast<uint8_t *>(h->io_rake.p), s);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(mask_out, h->io_rake.p, n_frames, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return AEGIS_OK;
+}
+
+// ---- streaming -------------------------------------------------------------------------------
+static int stream_run(aegis_stream *st, int64_t f_lo, int64_t f_hi, bool final_pass, hipStream_t s) {
+    // analyses frames [f_lo, f_hi) and advances the Viterbi over them; final_pass also finishes the
+    // back-trace and the clip-global stages
+    aegis_handle *h = st->h;
+    const Tables &t = h->tab;
+    const int S = 2 * t.n_bins;
+    const int64_t Ftot = final_pass ? f_hi : st->cap_frames;     // clip length as far as the kernels know
+    // meta layout (int64): sample_off[2] | frame_off[2] | sel_off[2] | chunk_off[2] | order (int32 in one slot)
+    st->host_meta.assign(9, 0);
+    st->host_meta[1] = st->n_samples;
+    st->host_meta[3] = Ftot;
+    st->host_meta[5] = f_hi - f_lo;
+    st->host_meta[7] = (Ftot - 1 + kViterbiChunk - 1) / kViterbiChunk;
+    HIPCHK(h, hipMemcpyAsync(st->meta.p, st->host_meta.data(), 9 * 8, hipMemcpyHostToDevice, s));
+    const int64_t *dm = static_cast<const int64_t *>(st->meta.p);
+    PassParams p = base_params(t);
+    p.stages = AEGIS_STAGE_ALL;
+    p.pcm = static_cast<const float *>(st->pcm.p);
+    p.sample_off = dm; p.frame_off = dm + 2; p.sel_off = dm + 4;
+    p.chunk_off = const_cast<int64_t *>(dm + 6);
+    p.order = reinterpret_cast<const int32_t *>(dm + 8);
+    p.n_clips = 1; p.n_frames = Ftot;
+    p.t_begin = f_lo; p.n_sel = f_hi - f_lo;
+    p.vt_begin = f_lo; p.vt_end = final_pass ? INT64_MAX : f_hi;
+    p.acf = static_cast<double *>(st->acf.p); p.lag_stride = h->lag_stride;
+    p.yin = static_cast<double *>(st->yin.p); p.yin_stride = h->yin_stride;
+    p.logobs = static_cast<double *>(st->logobs.p); p.obs_stride = h->obs_stride;
+    p.logunv = static_cast<double *>(st->logunv.p);
+    p.ptr = static_cast<uint16_t *>(st->ptr.p); p.cmap = static_cast<uint16_t *>(st->cmap.p);
+    p.bnd = static_cast<int32_t *>(st->bnd.p); p.states = static_cast<int32_t *>(st->states.p);
+    p.live_states = static_cast<int32_t *>(st->live.p);
+    p.melpow = static_cast<float *>(st->melpow.p); p.clipmax = static_cast<uint32_t *>(st->clipmax.p);
+    p.rake_raw = static_cast<uint8_t *>(st->rake_raw.p);
+    p.vstate = static_cast<double *>(st->vstate.p);
+    p.out_vprob = static_cast<double *>(st->o_vprob.p);
+    p.out_rms = static_cast<float *>(st->o_rms.p);
+    p.out_f0 = static_cast<double *>(st->o_f0.p); p.out_voiced = static_cast<uint8_t *>(st->o_voiced.p);
+    p.out_rake = static_cast<uint8_t *>(st->o_rake.p); p.out_sdb = static_cast<float *>(st->o_sdb.p);
+    p.rake_ratio = 0.6;
+    const double ms_per_frame = ((double)t.hop / (double)t.sr) * 1000;
+    p.rake_min_frames = (int)(10 / ms_per_frame); p.rake_max_frames = (int)(30 / ms_per_frame);
+    (void)S;
+    if (p.n_sel > 0) {
+        launch_frame_fft(p, h->dt, s);
+        launch_yin_seq(p, h->dt, s);
+        launch_pyin_obs(p, h->dt, s);
+    }
+    if (p.n_sel > 0 || final_pass) {
+        hipError_t ve = launch_viterbi(p, h->dt, t.log_trans_band.data(), s);
+        if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+    }
+    HIPCHK(h, hipGetLastError());
+    return AEGIS_OK;
+}
+
+int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) {
+    if (!h || !out || max_samples <= 0) { if (h) h->err = "bad argument"; return AEGIS_ERR_INVALID; }
+    *out = nullptr;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    auto *st = new (std::nothrow) aegis_stream();
+    if (!st) { h->err = "out of host memory"; return AEGIS_ERR_NOMEM; }
+    st->h = h;
+    const Tables &t = h->tab;
+    st->cap_samples = max_samples;
+    st->cap_frames = 1 + max_samples / t.hop;
+    const int64_t F = st->cap_frames, S = 2 * t.n_bins;
+    const int64_t nch = (F - 1 + kViterbiChunk - 1) / kViterbiChunk + 1;
+    int rc = AEGIS_OK;
+    auto need = [&](DevBuf &b, size_t bytes) { if (rc == AEGIS_OK) rc = ensure(h, b, bytes); };
+    need(st->pcm, max_samples * 4); need(st->acf, F * h->lag_stride * 8); need(st->yin, F * h->yin_stride * 8);
+    need(st->logobs, F * h->obs_stride * 8); need(st->logunv, F * 8); need(st->ptr, F * S * 2);
+    need(st->cmap, nch * S * 2); need(st->bnd, nch * 4); need(st->states, F * 4); need(st->live, F * 4);
+    need(st->melpow, F * t.n_mels * 4); need(st->clipmax, 16); need(st->rake_raw, F); need(st->vstate, S * 8);
+    need(st->meta, 9 * 8);
+    need(st->o_f0, F * 8); need(st->o_voiced, F); need(st->o_vprob, F * 8); need(st->o_rms, F * 4); need(st->o_rake, F);
+    need(st->o_sdb, F * t.n_mels * 4);
+    if (rc != AEGIS_OK) { aegis_stream_free(st); return rc; }
+    HIPCHK(h, hipMemsetAsync(st->clipmax.p, 0, 16, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    *out = st;
+    return AEGIS_OK;
+}
+
+void aegis_stream_free(aegis_stream *st) {
+    if (!st) return;
+    if (st->h && st->h->device >= 0) { (void)hipSetDevice(st->h->device); (void)hipStreamSynchronize(st->h->stream); }
+    for (DevBuf *b : {&st->pcm, &st->acf, &st->yin, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
+                      &st->live, &st->melpow, &st->clipmax, &st->rake_raw, &st->vstate, &st->meta, &st->o_f0, &st->o_voiced,
+                      &st->o_vprob, &st->o_rms, &st->o_rake, &st->o_sdb})
+        free_buf(*b);
+    delete st;
+}
+
+int aegis_stream_push(aegis_stream *st, const float *samples, int64_t n, aegis_stream_frames *out, int64_t *n_frames) {
+    if (!st || !st->h) return AEGIS_ERR_INVALID;
+    aegis_handle *h = st->h;
+    if (n < 0 || (n > 0 && !samples) || !n_frames) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
+    if (st->closed) { h->err = "stream is closed"; return AEGIS_ERR_INVALID; }
+    if (st->n_samples + n > st->cap_samples) { h->err = "stream capacity exceeded"; return AEGIS_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (n > 0)
+        HIPCHK(h, hipMemcpyAsync(static_cast<float *>(st->pcm.p) + st->n_samples, samples, n * 4, hipMemcpyHostToDevice, s));
+    st->n_samples += n;
+    // frames whose centred window [t*hop - 1024, t*hop + 1024) is complete
+    const int hop = h->tab.hop;
+    const int64_t ready = st->n_samples >= kFrameLength / 2 ? (st->n_samples - kFrameLength / 2) / hop + 1 : 0;
+    const int64_t lo = st->frames_done, hi = std::max(lo, ready);
+    *n_frames = hi - lo;
+    if (hi > lo) {
+        int rc = stream_run(st, lo, hi, false, s);
+        if (rc != AEGIS_OK) return rc;
+        st->frames_done = hi;
+        if (out) {
+            const int64_t k = hi - lo;
+            if (out->rms) HIPCHK(h, hipMemcpyAsync(out->rms, static_cast<float *>(st->o_rms.p) + lo, k * 4, hipMemcpyDeviceToHost, s));
+            if (out->voiced_prob) HIPCHK(h, hipMemcpyAsync(out->voiced_prob, static_cast<double *>(st->o_vprob.p) + lo, k * 8, hipMemcpyDeviceToHost, s));
+            if (out->live_state) HIPCHK(h, hipMemcpyAsync(out->live_state, static_cast<int32_t *>(st->live.p) + lo, k * 4, hipMemcpyDeviceToHost, s));
+        }
+    }
+    HIPCHK(h, hipStreamSynchronize(s));
+    return AEGIS_OK;
+}
+
+int aegis_stream_close(aegis_stream *st, double rake_sensitivity, aegis_outputs *out, int64_t *n_frames) {
+    if (!st || !st->h) return AEGIS_ERR_INVALID;
+    aegis_handle *h = st->h;
+    if (!n_frames) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
+    if (st->closed) { h->err = "stream is closed"; return AEGIS_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const Tables &t = h->tab;
+    const int64_t F = 1 + st->n_samples / t.hop;
+    int rc = stream_run(st, st->frames_done, F, true, s);       // zero-padded tail frames + back-trace
+    if (rc != AEGIS_OK) return rc;
+    // clip-global stages over all F frames
+    st->host_meta[5] = F;
+    PassParams p = base_params(t);
+    p.stages = AEGIS_STAGE_ALL;
+    const int64_t *dm = static_cast<const int64_t *>(st->meta.p);
+    p.sample_off = dm; p.frame_off = dm + 2; p.sel_off = dm + 2; p.n_clips = 1; p.n_frames = F; p.n_sel = F;
+    p.states = static_cast<int32_t *>(st->states.p);
+    p.melpow = static_cast<float *>(st->melpow.p); p.clipmax = static_cast<uint32_t *>(st->clipmax.p);
+    p.rake_raw = static_cast<uint8_t *>(st->rake_raw.p);
+    p.out_f0 = static_cast<double *>(st->o_f0.p); p.out_voiced = static_cast<uint8_t *>(st->o_voiced.p);
+    p.out_rake = static_cast<uint8_t *>(st->o_rake.p); p.out_sdb = static_cast<float *>(st->o_sdb.p);
+    p.rake_ratio = rake_sensitivity;
+    const double ms_per_frame = ((double)t.hop / (double)t.sr) * 1000;
+    p.rake_min_frames = (int)(10 / ms_per_frame); p.rake_max_frames = (int)(30 / ms_per_frame);
+    launch_finalize_mel(p, h->dt, s);
+    launch_decode(p, h->dt, s);
+    HIPCHK(h, hipGetLastError());
+    st->frames_done = F;
+    st->closed = true;
+    *n_frames = F;
+    if (out) {
+        auto back = [&](void *dst, const void *src, size_t bytes) { return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s) : hipSuccess; };
+        HIPCHK(h, back(out->f0, st->o_f0.p, F * 8)); HIPCHK(h, back(out->voiced_flag, st->o_voiced.p, F));
+        HIPCHK(h, back(out->voiced_prob, st->o_vprob.p, F * 8)); HIPCHK(h, back(out->rms, st->o_rms.p, F * 4));
+        HIPCHK(h, back(out->rake_mask, st->o_rake.p, F)); HIPCHK(h, back(out->S_dB, st->o_sdb.p, (size_t)F * t.n_mels * 4));
+    }
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;
 }

@@ -48,6 +48,7 @@ struct PassParams {
     // Viterbi step range of this launch: t in [max(1, vt_begin), min(T, vt_end)); state carried in vstate
     int64_t vt_begin, vt_end;
     double *vstate;              // [n_clips][2*n_bins] column of values at the end of the previous launch
+    int32_t *live_states;        // optional [F]: arg-max state of each column as it is produced (streaming preview)
     // workspace (strides in elements)
     double *acf;   int32_t lag_stride;   // [F][lag_stride]   lags 0..max_period
     double *yin;   int32_t yin_stride;   // [F][yin_stride]   CMND for lags min..max

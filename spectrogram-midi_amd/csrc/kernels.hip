@@ -658,6 +658,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
         par ^= 1;
     };
     block_argmax(myv, act ? j : 0x7fffffff);
+    if (p.live_states != nullptr && tid == 0 && p.vt_begin == 0) p.live_states[f0] = kg;
 
     double *cur = val, *nxt = val + SP;
     for (int t = t_lo; t < t_hi; ++t) {
@@ -689,12 +690,14 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
             ptr[(int64_t)t * S + j] = (uint16_t)bi;
         }
         block_argmax(myv, act ? j : 0x7fffffff);
+        if (p.live_states != nullptr && tid == 0) p.live_states[f0 + t] = kg;
         double *tmp = cur; cur = nxt; nxt = tmp;
         if (t % C == 0 || t == T - 1) {
             const int cc = (t - 1) / C;
             if (act) {
                 int s = j;
-                for (int tt = t; tt > cc * C; --tt) s = ring[((tt - 1) % C) * S + s];
+                for (int tt = t; tt > cc * C; --tt)      // steps of an earlier launch (streaming): pointers from HBM
+                    s = tt >= t_lo ? ring[((tt - 1) % C) * S + s] : ptr[(int64_t)tt * S + s];
                 cmap[(int64_t)cc * S + j] = (uint16_t)s;
             }
             __syncthreads();
@@ -880,6 +883,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         par ^= 1;
     };
     end_of_step(myv, observed);
+    if (p.live_states != nullptr && tid == 0 && p.vt_begin == 0) p.live_states[f0] = kg;
 
     int cur = 0;
     for (int t = t_lo; t < t_hi; ++t) {
@@ -1054,12 +1058,14 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             ptr[(int64_t)t * S + j] = (uint16_t)bi;
         }
         end_of_step(myv, observed);
+        if (p.live_states != nullptr && tid == 0) p.live_states[f0 + t] = kg;
         cur ^= 1;
         if (t % C == 0 || t == T - 1) {
             const int cc = (t - 1) / C;
             if (act) {
                 int s = j;
-                for (int tt = t; tt > cc * C; --tt) s = ring[((tt - 1) % C) * S + s];
+                for (int tt = t; tt > cc * C; --tt)      // steps of an earlier launch (streaming): pointers from HBM
+                    s = tt >= t_lo ? ring[((tt - 1) % C) * S + s] : ptr[(int64_t)tt * S + s];
                 cmap[(int64_t)cc * S + j] = (uint16_t)s;
             }
             __syncthreads();
