@@ -104,6 +104,16 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
 int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int64_t n_frames,
                         double broadband_threshold_ratio, uint8_t *mask_out);
 
+/* --- constant-Q magnitudes (BASELINE.json configs[2]) --------------------------------
+ * The reference's only CQT is librosa.feature.chroma_cqt inside the auto-matcher score
+ * (aegis_engine_core/auto_matcher.py:68-69).  This computes the DIRECT transform librosa.cqt(hop_length=hop,
+ * fmin, n_bins, bins_per_octave, filter_scale, norm=1, window='hann', scale=True, pad_mode='constant')
+ * approximates octave by octave (wavelet atoms of librosa 0.10 filters.wavelet), as a block-sparse float32
+ * GEMM on the MFMA units.  Host PCM in, |C| out: per clip [n_bins, F_clip] C-order, clip after clip.
+ * Zero arguments take the defaults n_bins=84, bins_per_octave=12, fmin=C1, filter_scale=1.  Blocking. */
+int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
+              int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out);
+
 /* --- incremental analysis of one clip (BASELINE.json configs[4]; the reference has no streaming path:
  * financial_app_realtime.py analyses whole files).  Samples are pushed in any chunk sizes; every frame whose
  * centred 2048-sample window is complete is analysed at once (mel, YIN, observation) and the Viterbi advances

@@ -38,7 +38,7 @@ class Outputs(C.Structure):
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
            "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend",
-           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free")
+           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt")
 
 _lib = None
 
@@ -81,6 +81,9 @@ def load():
     lib.aegis_stream_close.restype = C.c_int
     lib.aegis_stream_free.argtypes = [C.c_void_p]
     lib.aegis_stream_free.restype = None
+    lib.aegis_cqt.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
+                              C.c_double, C.c_double, C.c_void_p]
+    lib.aegis_cqt.restype = C.c_int
     lib.aegis_set_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_set_table.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -257,6 +260,24 @@ class Handle:
         self._check(self.lib.aegis_trend(self._h, int(op), flat.ctypes.data, off.ctypes.data, len(lens),
                                          par.ctypes.data, len(par), ptrs, n_out))
         return [[o[off[i]:off[i + 1]] for i in range(len(lens))] for o in outs]
+
+    def cqt(self, clips, n_bins=84, bins_per_octave=12, fmin=32.70319566257483, filter_scale=1.0):
+        """|CQT| of each clip, float32 [n_bins, 1 + len//hop] (aegis_cqt: direct transform on the MFMA units)."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        n = len(clips)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in clips])
+        lens = (C.c_int64 * n)(*[len(c) for c in clips])
+        frames = [self.frames_for(len(c)) for c in clips]
+        out = np.empty(sum(frames) * n_bins, np.float32)
+        self._check(self.lib.aegis_cqt(self._h, ptrs, lens, n, n_bins, bins_per_octave, float(fmin), float(filter_scale),
+                                       out.ctypes.data))
+        res, o = [], 0
+        for Fc in frames:
+            res.append(out[o:o + Fc * n_bins].reshape(n_bins, Fc).copy())
+            o += Fc * n_bins
+        return res
 
     def open_stream(self, max_seconds=600.0):
         return Stream(self, int(max_seconds * self.sr))

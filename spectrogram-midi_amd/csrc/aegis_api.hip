@@ -16,6 +16,7 @@
 
 #include "../../include/aegis_hip.h"
 #include "kernels.h"
+#include "cqt.h"
 #include "tables.h"
 #include "trend.h"
 
@@ -50,6 +51,8 @@ struct aegis_handle {
     // workspace (grow-only)
     DevBuf acf, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
     DevBuf sample_off, frame_off, order, sel_off, vstate;
+    CqtBank cqt_bank;
+    DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
     DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb;
     int32_t lag_stride = 0, yin_stride = 0, obs_stride = 0;
@@ -209,6 +212,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CRTHIP(viterbi_configure());
+    CRTHIP(cqt_configure());
 
     const Tables &t = h->tab;
     CRT(upload_table(h, t.hann, &h->dt.hann));
@@ -243,10 +247,11 @@ void aegis_destroy(aegis_handle *h) {
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (void *p : h->table_allocs) (void)hipFree(p);
+    if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
     for (DevBuf *b : {&h->acf, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
                       &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
                       &h->order, &h->sel_off, &h->vstate, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
-                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
+                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb})
         free_buf(*b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -539,6 +544,59 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(mask_out, h->io_rake.p, n_frames, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    return AEGIS_OK;
+}
+
+int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
+              int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out) {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !mag_out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    if (n_clips == 0) return AEGIS_OK;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    if (n_bins == 0) n_bins = 84;
+    if (bins_per_octave == 0) bins_per_octave = 12;
+    if (!(fmin > 0)) fmin = 32.70319566257483;            // note_to_hz('C1')
+    if (!(filter_scale > 0)) filter_scale = 1.0;
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    CqtBank &b = h->cqt_bank;
+    if (b.n_bins != n_bins || b.bins_per_octave != bins_per_octave || b.fmin != fmin || b.filter_scale != filter_scale || !b.dev) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (b.dev) { (void)hipFree(b.dev); b.dev = nullptr; }
+        const char *msg = build_cqt_bank(b, h->tab.sr, n_bins, fmin, bins_per_octave, filter_scale);
+        if (msg[0]) { h->err = msg; b.n_bins = 0; return AEGIS_ERR_INVALID; }
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&b.dev), b.data.size() * 4));
+        HIPCHK(h, hipMemcpy(b.dev, b.data.data(), b.data.size() * 4, hipMemcpyHostToDevice));
+    }
+    std::vector<int64_t> soff(n_clips + 1, 0), foff(n_clips + 1, 0), toff(n_clips + 1, 0);
+    for (int i = 0; i < n_clips; ++i) {
+        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) { h->err = "bad clip " + std::to_string(i); return AEGIS_ERR_INVALID; }
+        soff[i + 1] = soff[i] + n_samples[i];
+        foff[i + 1] = foff[i] + 1 + n_samples[i] / h->tab.hop;
+        toff[i + 1] = toff[i] + (1 + n_samples[i] / h->tab.hop + kCqtSlideFrames - 1) / kCqtSlideFrames;
+    }
+    const int64_t F = foff[n_clips];
+    int rc;
+    if ((rc = ensure(h, h->q_pcm, (size_t)std::max<int64_t>(soff[n_clips], 1) * 4)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_soff, (n_clips + 1) * 8)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_foff, (n_clips + 1) * 8)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_toff, (n_clips + 1) * 8)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_out, (size_t)F * n_bins * 4)) != AEGIS_OK) return rc;
+    for (int i = 0; i < n_clips; ++i)
+        if (n_samples[i] > 0)
+            HIPCHK(h, hipMemcpyAsync(static_cast<float *>(h->q_pcm.p) + soff[i], pcm[i], n_samples[i] * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->q_soff.p, soff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->q_foff.p, foff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->q_toff.p, toff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
+    CqtArgs a{static_cast<const float *>(h->q_pcm.p), static_cast<const int64_t *>(h->q_soff.p),
+              static_cast<const int64_t *>(h->q_foff.p), n_clips, F, h->tab.hop, static_cast<float *>(h->q_out.p)};
+    if (h->profiling) { for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); } h->events.clear(); }
+    begin_event(h, "cqt", s); launch_cqt(a, b, static_cast<const int64_t *>(h->q_toff.p), toff[n_clips], s); end_event(h, s);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(mag_out, h->q_out.p, (size_t)F * n_bins * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (h->profiling) collect_events(h);
     return AEGIS_OK;
 }
 
