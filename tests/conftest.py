@@ -11,6 +11,14 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a clean checkout has no built artefacts (they are git-ignored): build them once (hipcc cross-compiles
+    # gfx950 without a GPU; the oracle's C helper needs gcc only)
+    lib = os.path.join(ROOT, "spectrogram-midi_amd", "libaegis_hip.so")
+    helper = os.path.join(ROOT, "oracle", "_build", "liboracle.so")
+    if not (os.path.exists(lib) and os.path.exists(helper)):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "spectrogram-midi_amd", "csrc")], check=True)
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 
 def _have_gpu():
