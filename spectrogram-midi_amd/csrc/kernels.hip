@@ -334,6 +334,59 @@ __global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
     }
 }
 
+// Latency variant of kernel 2 for small selections (streaming pushes): one frame per 128-thread
+// workgroup.  The frame is staged in LDS; the two float32 running sums (cumsum up to 1024+tau, cumsum up
+// to tau) are walked by lane 0 of wave 0 and of wave 1 concurrently, the difference function is formed in
+// parallel, only the float64 cumsum of d stays serial, and the CMND quotient is parallel again.  Same
+// operations in the same order as yin_seq_kernel: bit-identical output.
+__global__ __launch_bounds__(128) void yin_seq_wave_kernel(PassParams p) {
+    __shared__ float xs[2048];
+    __shared__ float ehi[1024], elo[1024];
+    __shared__ double dd[1024], cs[1024];
+    const int tid = threadIdx.x;
+    int c;
+    int64_t t, f;
+    map_frame(p, (int64_t)blockIdx.x, c, t, f);
+    const int64_t base = p.sample_off[c];
+    const int64_t n = p.sample_off[c + 1] - base;
+    const int64_t start = t * p.hop - 1024;
+    for (int i = tid; i < 2048; i += 128) {
+        const int64_t idx = start + i;
+        xs[i] = (idx >= 0 && idx < n) ? p.pcm[base + idx] : 0.0f;
+    }
+    __syncthreads();
+    const int mp = p.max_period;
+    if (tid == 0) {
+        float e = 0.0f;
+        for (int k = 0; k < 1024; ++k) { const float sq = xs[k] * xs[k]; e = (k == 0) ? sq : e + sq; }
+        for (int tau = 0; tau <= mp; ++tau) { const float v = xs[1024 + tau]; e = e + v * v; ehi[tau] = e; }
+    } else if (tid == 64) {
+        float e = 0.0f;
+        for (int tau = 0; tau <= mp; ++tau) { const float sq = xs[tau] * xs[tau]; e = (tau == 0) ? sq : e + sq; elo[tau] = e; }
+    }
+    __syncthreads();
+    const double *__restrict__ acf = p.acf + f * (int64_t)p.lag_stride;
+    float en0 = ehi[0] - elo[0];
+    if (fabsf(en0) < 1e-6f) en0 = 0.0f;
+    for (int tau = tid; tau <= mp; tau += 128) {
+        float en = ehi[tau] - elo[tau];
+        if (fabsf(en) < 1e-6f) en = 0.0f;
+        double a = acf[tau];
+        if (fabs(a) < 1e-6) a = 0.0;
+        const float esum = en0 + en;
+        dd[tau] = (double)esum - 2.0 * a;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int tau = 1; tau <= mp; ++tau) { s = (tau == 1) ? dd[1] : s + dd[tau]; cs[tau] = s; }
+    }
+    __syncthreads();
+    double *__restrict__ yin = p.yin + f * (int64_t)p.yin_stride;
+    for (int tau = p.min_period + tid; tau <= mp; tau += 128)
+        yin[tau - p.min_period] = dd[tau] / (cs[tau] / (double)tau + DBL_MIN);
+}
+
 // ------------------------------------------------------------------------------------------
 // Kernel 3: one frame per wave.  Troughs of the CMND, the Beta/Boltzmann threshold prior,
 // parabolic refinement, pitch-bin observation row in the log domain.
@@ -1270,6 +1323,10 @@ void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
 }
 void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
     if (p.n_sel == 0) return;
+    if (p.n_sel <= 32) {     // a streaming push: a handful of frames, latency matters
+        hipLaunchKernelGGL(yin_seq_wave_kernel, dim3((unsigned)p.n_sel), dim3(128), 0, s, p);
+        return;
+    }
     hipLaunchKernelGGL(yin_seq_kernel, dim3((unsigned)((p.n_sel + 63) / 64)), dim3(64), 0, s, p);
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
