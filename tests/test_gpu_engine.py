@@ -109,10 +109,11 @@ def test_detect_rake_patterns_against_reference_goldens(eng):
     np.testing.assert_array_equal(eng.detect_rake_patterns(G["S_0"]), orake.detect_rake_patterns(G["S_0"], 512, 44100, 0.6))
 
 
-@pytest.mark.parametrize("sr,hop", [(22050, 512), (44100, 256), (48000, 512), (44100, 1024)])
+@pytest.mark.parametrize("sr,hop", [(22050, 512), (44100, 256), (48000, 512), (44100, 1024), (44100, 441)])
 def test_other_rates_and_hops(sr, hop):
     """v2 engine rate (aegis_engine_financial.py:36) uses the H=50 band kernel; the others take
-    the generic Viterbi kernel (transition widths 31, 51@48k, 101)."""
+    the generic Viterbi kernel (transition widths 31, 51@48k, 101); hop 441 is not a multiple of 4 samples, so
+    the YIN walk takes its scalar-load path."""
     y = signals.guitar_clip(4.0, sr=sr, seed=9)
     h = _lib.Handle(sample_rate=sr, hop_length=hop)
     r = h.analyze_batch([y])[0]
@@ -168,3 +169,23 @@ def test_batch_properties_at_scale():
     with pytest.raises(_lib.AegisError):
         small.analyze_batch([np.zeros(4001 * 512, np.float32)])   # one clip larger than a pass
     h.close(); small.close()
+
+
+def test_unaligned_clips_and_fewer_mel_bands():
+    """Clips whose packed offsets are not multiples of 4 samples (scalar-load path of the YIN walk) and a
+    64-band mel bank."""
+    y1, y2 = signals.guitar_clip(1.0, seed=41)[:44101], signals.guitar_clip(1.5, seed=42)[:60003]
+    h = _lib.Handle()
+    a = h.analyze_batch([y1, y2])
+    for r, y in zip(a, (y1, y2)):
+        f0, vf, vp = opyin.pyin(y)
+        np.testing.assert_array_equal(r["voiced_flag"], vf)
+        np.testing.assert_array_equal(r["voiced_prob"], vp)
+        np.testing.assert_array_equal(r["rms"], odsp.rms(y))
+    h.close()
+    h64 = _lib.Handle(n_mels=64)
+    r = h64.analyze_batch([y2], stages=_lib.STAGE_MEL)[0]
+    ref = odsp.power_to_db(odsp.melspectrogram(y2, n_mels=64))
+    assert r["S_dB"].shape == ref.shape == (64, 118)
+    np.testing.assert_allclose(r["S_dB"], ref, atol=2e-3)
+    h64.close()
