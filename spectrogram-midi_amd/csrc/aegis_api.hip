@@ -80,6 +80,14 @@ struct aegis_stream {
     DevBuf pcm, acf, yin, logobs, logunv, ptr, cmap, bnd, states, live, melpow, clipmax, rake_raw, vstate, meta;
     DevBuf o_f0, o_voiced, o_vprob, o_rms, o_rake, o_sdb;
     std::vector<int64_t> host_meta;
+    // captured hipGraph of one fixed-size push (built lazily for the first push size that is a multiple of hop)
+    DevBuf ctl, g_staging, g_result;
+    float *pin_samples = nullptr;
+    unsigned char *pin_result = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int64_t graph_push = 0;
+    bool graph_failed = false;
 };
 
 namespace {
@@ -601,30 +609,16 @@ int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples
 }
 
 // ---- streaming -------------------------------------------------------------------------------
-static int stream_run(aegis_stream *st, int64_t f_lo, int64_t f_hi, bool final_pass, hipStream_t s) {
-    // analyses frames [f_lo, f_hi) and advances the Viterbi over them; final_pass also finishes the
-    // back-trace and the clip-global stages
+static PassParams stream_params(aegis_stream *st, const int64_t *dm) {
     aegis_handle *h = st->h;
     const Tables &t = h->tab;
-    const int S = 2 * t.n_bins;
-    const int64_t Ftot = final_pass ? f_hi : st->cap_frames;     // clip length as far as the kernels know
-    // meta layout (int64): sample_off[2] | frame_off[2] | sel_off[2] | chunk_off[2] | order (int32 in one slot)
-    st->host_meta.assign(9, 0);
-    st->host_meta[1] = st->n_samples;
-    st->host_meta[3] = Ftot;
-    st->host_meta[5] = f_hi - f_lo;
-    st->host_meta[7] = (Ftot - 1 + kViterbiChunk - 1) / kViterbiChunk;
-    HIPCHK(h, hipMemcpyAsync(st->meta.p, st->host_meta.data(), 9 * 8, hipMemcpyHostToDevice, s));
-    const int64_t *dm = static_cast<const int64_t *>(st->meta.p);
     PassParams p = base_params(t);
     p.stages = AEGIS_STAGE_ALL;
     p.pcm = static_cast<const float *>(st->pcm.p);
     p.sample_off = dm; p.frame_off = dm + 2; p.sel_off = dm + 4;
     p.chunk_off = const_cast<int64_t *>(dm + 6);
     p.order = reinterpret_cast<const int32_t *>(dm + 8);
-    p.n_clips = 1; p.n_frames = Ftot;
-    p.t_begin = f_lo; p.n_sel = f_hi - f_lo;
-    p.vt_begin = f_lo; p.vt_end = final_pass ? INT64_MAX : f_hi;
+    p.n_clips = 1;
     p.acf = static_cast<double *>(st->acf.p); p.lag_stride = h->lag_stride;
     p.yin = static_cast<double *>(st->yin.p); p.yin_stride = h->yin_stride;
     p.logobs = static_cast<double *>(st->logobs.p); p.obs_stride = h->obs_stride;
@@ -642,6 +636,58 @@ static int stream_run(aegis_stream *st, int64_t f_lo, int64_t f_hi, bool final_p
     p.rake_ratio = 0.6;
     const double ms_per_frame = ((double)t.hop / (double)t.sr) * 1000;
     p.rake_min_frames = (int)(10 / ms_per_frame); p.rake_max_frames = (int)(30 / ms_per_frame);
+    return p;
+}
+
+// Captures one fixed-size push as a hipGraph: H2D of the samples, advance (append + geometry), the four
+// analysis kernels reading their geometry from the device control block, result gather, D2H.
+static bool stream_build_graph(aegis_stream *st, int64_t n_push, hipStream_t s) {
+    aegis_handle *h = st->h;
+    const Tables &t = h->tab;
+    if (!st->pin_samples || !st->pin_result || n_push > 8192 || n_push % t.hop != 0 || n_push / t.hop + 1 > 8) return false;
+    StreamCtl *ctl = static_cast<StreamCtl *>(st->ctl.p);
+    PassParams p = stream_params(st, ctl->meta);      // device address arithmetic only
+    p.ctl = ctl;
+    p.n_frames = st->cap_frames;
+    p.n_sel = n_push / t.hop + 1;                       // launch sizes; the kernels clamp to ctl->n_sel
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) return false;
+    bool ok = true;
+    ok &= hipMemcpyAsync(st->g_staging.p, st->pin_samples, n_push * 4, hipMemcpyHostToDevice, s) == hipSuccess;
+    launch_stream_advance(ctl, static_cast<const float *>(st->g_staging.p), (int)n_push, static_cast<float *>(st->pcm.p), t.hop, s);
+    launch_frame_fft(p, h->dt, s);
+    launch_yin_seq(p, h->dt, s);
+    launch_pyin_obs(p, h->dt, s);
+    ok &= launch_viterbi(p, h->dt, t.log_trans_band.data(), s) == hipSuccess;
+    launch_stream_gather(ctl, p.out_rms, p.out_vprob, p.live_states, st->g_result.p, s);
+    ok &= hipMemcpyAsync(st->pin_result, st->g_result.p, 256, hipMemcpyDeviceToHost, s) == hipSuccess;
+    hipGraph_t g = nullptr;
+    ok &= hipStreamEndCapture(s, &g) == hipSuccess && g != nullptr;
+    if (!ok) { if (g) (void)hipGraphDestroy(g); (void)hipGetLastError(); return false; }
+    hipGraphExec_t ex = nullptr;
+    if (hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); (void)hipGetLastError(); return false; }
+    st->graph = g; st->graph_exec = ex; st->graph_push = n_push;
+    return true;
+}
+
+static int stream_run(aegis_stream *st, int64_t f_lo, int64_t f_hi, bool final_pass, hipStream_t s) {
+    // analyses frames [f_lo, f_hi) and advances the Viterbi over them; final_pass also finishes the
+    // back-trace and the clip-global stages
+    aegis_handle *h = st->h;
+    const Tables &t = h->tab;
+    const int S = 2 * t.n_bins;
+    const int64_t Ftot = final_pass ? f_hi : st->cap_frames;     // clip length as far as the kernels know
+    // meta layout (int64): sample_off[2] | frame_off[2] | sel_off[2] | chunk_off[2] | order (int32 in one slot)
+    st->host_meta.assign(9, 0);
+    st->host_meta[1] = st->n_samples;
+    st->host_meta[3] = Ftot;
+    st->host_meta[5] = f_hi - f_lo;
+    st->host_meta[7] = (Ftot - 1 + kViterbiChunk - 1) / kViterbiChunk;
+    HIPCHK(h, hipMemcpyAsync(st->meta.p, st->host_meta.data(), 9 * 8, hipMemcpyHostToDevice, s));
+    const int64_t *dm = static_cast<const int64_t *>(st->meta.p);
+    PassParams p = stream_params(st, dm);
+    p.n_frames = Ftot;
+    p.t_begin = f_lo; p.n_sel = f_hi - f_lo;
+    p.vt_begin = f_lo; p.vt_end = final_pass ? INT64_MAX : f_hi;
     (void)S;
     if (p.n_sel > 0) {
         launch_frame_fft(p, h->dt, s);
@@ -676,12 +722,20 @@ int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) 
     need(st->logobs, F * h->obs_stride * 8); need(st->logunv, F * 8); need(st->ptr, F * S * 2);
     need(st->cmap, nch * S * 2); need(st->bnd, nch * 4); need(st->states, F * 4); need(st->live, F * 4);
     need(st->melpow, F * t.n_mels * 4); need(st->clipmax, 16); need(st->rake_raw, F); need(st->vstate, S * 8);
-    need(st->meta, 9 * 8);
+    need(st->meta, 9 * 8); need(st->ctl, sizeof(StreamCtl)); need(st->g_staging, 8192 * 4); need(st->g_result, 256);
     need(st->o_f0, F * 8); need(st->o_voiced, F); need(st->o_vprob, F * 8); need(st->o_rms, F * 4); need(st->o_rake, F);
     need(st->o_sdb, F * t.n_mels * 4);
     if (rc != AEGIS_OK) { aegis_stream_free(st); return rc; }
     HIPCHK(h, hipMemsetAsync(st->clipmax.p, 0, 16, h->stream));
+    {
+        StreamCtl c0{};
+        c0.meta[3] = st->cap_frames;
+        c0.meta[7] = (st->cap_frames - 1 + kViterbiChunk - 1) / kViterbiChunk;
+        HIPCHK(h, hipMemcpyAsync(st->ctl.p, &c0, sizeof(c0), hipMemcpyHostToDevice, h->stream));
+    }
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (hipHostMalloc(reinterpret_cast<void **>(&st->pin_samples), 8192 * 4, hipHostMallocDefault) != hipSuccess) st->pin_samples = nullptr;
+    if (hipHostMalloc(reinterpret_cast<void **>(&st->pin_result), 256, hipHostMallocDefault) != hipSuccess) st->pin_result = nullptr;
     *out = st;
     return AEGIS_OK;
 }
@@ -689,7 +743,11 @@ int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) 
 void aegis_stream_free(aegis_stream *st) {
     if (!st) return;
     if (st->h && st->h->device >= 0) { (void)hipSetDevice(st->h->device); (void)hipStreamSynchronize(st->h->stream); }
-    for (DevBuf *b : {&st->pcm, &st->acf, &st->yin, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
+    if (st->graph_exec) (void)hipGraphExecDestroy(st->graph_exec);
+    if (st->graph) (void)hipGraphDestroy(st->graph);
+    if (st->pin_samples) (void)hipHostFree(st->pin_samples);
+    if (st->pin_result) (void)hipHostFree(st->pin_result);
+    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->acf, &st->yin, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
                       &st->live, &st->melpow, &st->clipmax, &st->rake_raw, &st->vstate, &st->meta, &st->o_f0, &st->o_voiced,
                       &st->o_vprob, &st->o_rms, &st->o_rake, &st->o_sdb})
         free_buf(*b);
@@ -705,6 +763,30 @@ int aegis_stream_push(aegis_stream *st, const float *samples, int64_t n, aegis_s
     std::lock_guard<std::mutex> lock(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
+    // ---- fixed-size pushes replay a captured hipGraph ---------------------------------------------
+    const bool eligible = n > 0 && n <= 8192 && n % h->tab.hop == 0 && n / h->tab.hop + 1 <= 8;
+    if (eligible && !st->graph_failed && (st->graph_exec == nullptr || st->graph_push == n)) {
+        if (st->graph_exec == nullptr && !stream_build_graph(st, n, s)) st->graph_failed = true;
+        if (st->graph_exec != nullptr && st->graph_push == n) {
+            std::memcpy(st->pin_samples, samples, (size_t)n * 4);
+            HIPCHK(h, hipGraphLaunch(st->graph_exec, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            st->n_samples += n;
+            const int64_t ready = st->n_samples >= kFrameLength / 2 ? (st->n_samples - kFrameLength / 2) / h->tab.hop + 1 : 0;
+            const int64_t lo = st->frames_done, hi = std::max(lo, ready);
+            int64_t got = 0;
+            std::memcpy(&got, st->pin_result, 8);
+            if (got != hi - lo) { h->err = "stream graph and host disagree on the frame count"; return AEGIS_ERR_DEVICE; }
+            st->frames_done = hi;
+            *n_frames = got;
+            if (out) {
+                if (out->rms) std::memcpy(out->rms, st->pin_result + 8, (size_t)got * 4);
+                if (out->voiced_prob) std::memcpy(out->voiced_prob, st->pin_result + 8 + 32, (size_t)got * 8);
+                if (out->live_state) std::memcpy(out->live_state, st->pin_result + 8 + 32 + 64, (size_t)got * 4);
+            }
+            return AEGIS_OK;
+        }
+    }
     if (n > 0)
         HIPCHK(h, hipMemcpyAsync(static_cast<float *>(st->pcm.p) + st->n_samples, samples, n * 4, hipMemcpyHostToDevice, s));
     st->n_samples += n;
@@ -723,6 +805,10 @@ int aegis_stream_push(aegis_stream *st, const float *samples, int64_t n, aegis_s
             if (out->voiced_prob) HIPCHK(h, hipMemcpyAsync(out->voiced_prob, static_cast<double *>(st->o_vprob.p) + lo, k * 8, hipMemcpyDeviceToHost, s));
             if (out->live_state) HIPCHK(h, hipMemcpyAsync(out->live_state, static_cast<int32_t *>(st->live.p) + lo, k * 4, hipMemcpyDeviceToHost, s));
         }
+    }
+    {   // the device control block of the graph path mirrors the host counters
+        const int64_t counters[2] = {st->n_samples, st->frames_done};
+        HIPCHK(h, hipMemcpyAsync(st->ctl.p, counters, 16, hipMemcpyHostToDevice, s));
     }
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;

@@ -24,6 +24,17 @@ struct DevTables {
     const double2 *twiddle;    // [2048]
 };
 
+// Device-resident geometry of a streaming push (captured hipGraph): when PassParams::ctl is set the
+// kernels take the selection / step range from here instead of the by-value fields, so the graph's
+// kernel nodes never need new parameters.  Advanced by stream_advance_kernel at the head of the graph.
+struct StreamCtl {
+    int64_t n_samples;        // samples received
+    int64_t frames_done;      // frames analysed
+    int64_t t_begin, n_sel;   // frames of the current push
+    int64_t vt_begin, vt_end; // Viterbi steps of the current push
+    int64_t meta[9];          // sample_off[2] | frame_off[2] | sel_off[2] | chunk_off[2] | order
+};
+
 // Geometry shared by all kernels of one pass.
 struct PassParams {
     // configuration
@@ -49,6 +60,7 @@ struct PassParams {
     int64_t vt_begin, vt_end;
     double *vstate;              // [n_clips][2*n_bins] column of values at the end of the previous launch
     int32_t *live_states;        // optional [F]: arg-max state of each column as it is produced (streaming preview)
+    const StreamCtl *ctl;        // optional: device-resident t_begin / n_sel / vt_begin / vt_end (graph replay)
     // workspace (strides in elements)
     double *acf;   int32_t lag_stride;   // [F][lag_stride]   lags 0..max_period
     double *yin;   int32_t yin_stride;   // [F][yin_stride]   CMND for lags min..max
@@ -79,6 +91,9 @@ void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_finalize_mel(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, int min_frames, int max_frames,
                          uint8_t *raw, uint8_t *out, hipStream_t s);
+void launch_stream_advance(StreamCtl *ctl, const float *staging, int n_push, float *pcm, int hop, hipStream_t s);
+void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *vprob, const int32_t *live, void *result,
+                          hipStream_t s);
 hipError_t viterbi_configure();   // raises the dynamic-LDS limit once
 
 }  // namespace aegis

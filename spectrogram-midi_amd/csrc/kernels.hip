@@ -32,10 +32,16 @@ __device__ __forceinline__ int find_clip(const int64_t *__restrict__ frame_off, 
     return lo;
 }
 
+// selection / step range of this launch: by-value fields, or the device control block of a graph replay
+__device__ __forceinline__ int64_t geo_n_sel(const PassParams &p) { return p.ctl ? p.ctl->n_sel : p.n_sel; }
+__device__ __forceinline__ int64_t geo_t_begin(const PassParams &p) { return p.ctl ? p.ctl->t_begin : p.t_begin; }
+__device__ __forceinline__ int64_t geo_vt_begin(const PassParams &p) { return p.ctl ? p.ctl->vt_begin : p.vt_begin; }
+__device__ __forceinline__ int64_t geo_vt_end(const PassParams &p) { return p.ctl ? p.ctl->vt_end : p.vt_end; }
+
 // selected-frame index of this launch -> (clip, frame within clip, frame within pass)
 __device__ __forceinline__ void map_frame(const PassParams &p, int64_t fs, int &c, int64_t &t, int64_t &f) {
     c = find_clip(p.sel_off, p.n_clips, fs);
-    t = p.t_begin + (fs - p.sel_off[c]);
+    t = geo_t_begin(p) + (fs - p.sel_off[c]);
     f = p.frame_off[c] + t;
 }
 
@@ -126,7 +132,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     float *xs = xs_all + hh * 2048, *pw = pw_all + hh * 1032, *red = red_all + hh * 128, *blk = blk_all + hh * 16;
 
     const int64_t fs = (int64_t)blockIdx.x * 2 + hh;
-    const bool live = fs < p.n_sel;
+    const bool live = fs < geo_n_sel(p);
     int c = 0;
     int64_t base = 0, n = 0, start = 0, f = 0;
     if (live) {
@@ -274,7 +280,7 @@ __device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, in
 
 __global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
     const int64_t fs = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (fs >= p.n_sel) return;
+    if (fs >= geo_n_sel(p)) return;
     int c;
     int64_t t, f;
     map_frame(p, fs, c, t, f);
@@ -344,6 +350,7 @@ __global__ __launch_bounds__(128) void yin_seq_wave_kernel(PassParams p) {
     __shared__ float ehi[1024], elo[1024];
     __shared__ double dd[1024], cs[1024];
     const int tid = threadIdx.x;
+    if ((int64_t)blockIdx.x >= geo_n_sel(p)) return;
     int c;
     int64_t t, f;
     map_frame(p, (int64_t)blockIdx.x, c, t, f);
@@ -433,6 +440,7 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     __shared__ double beta_s[104];
 
     const int lane = threadIdx.x;
+    if ((int64_t)blockIdx.x >= geo_n_sel(p)) return;
     int64_t f;
     {
         int c;
@@ -676,13 +684,15 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     const int dlo = max(0, H - b2);
     const int dhi = min(W - 1, B - 1 - b2 + H);
 
-    const int t_lo = (int)(p.vt_begin > 1 ? p.vt_begin : 1);
-    const int t_hi = (int)(p.vt_end < T ? p.vt_end : T);
-    if (p.vt_begin >= T && !(p.vt_begin == 0)) return;          // clip finished in an earlier launch
+    const int64_t vt_begin = geo_vt_begin(p), vt_end = geo_vt_end(p);
+    if (p.ctl && p.ctl->n_sel == 0) return;                     // graph replay of a push that completed no frame
+    const int t_lo = (int)(vt_begin > 1 ? vt_begin : 1);
+    const int t_hi = (int)(vt_end < T ? vt_end : T);
+    if (vt_begin >= T && vt_begin != 0) return;                 // clip finished in an earlier launch
     double *__restrict__ vst = p.vstate + (int64_t)c * S;
     double myv = -INFINITY;
     if (act) {
-        if (p.vt_begin == 0) {
+        if (vt_begin == 0) {
             const double lp = v2 ? lunv[0] : lobs[b2];
             myv = lp + p.log_pinit;
         } else {
@@ -711,7 +721,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
         par ^= 1;
     };
     block_argmax(myv, act ? j : 0x7fffffff);
-    if (p.live_states != nullptr && tid == 0 && p.vt_begin == 0) p.live_states[f0] = kg;
+    if (p.live_states != nullptr && tid == 0 && vt_begin == 0) p.live_states[f0] = kg;
 
     double *cur = val, *nxt = val + SP;
     for (int t = t_lo; t < t_hi; ++t) {
@@ -883,16 +893,18 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         else valI[(buf * 2 + vp) * PADB + b2c + H] = v;
     };
 
-    const int t_lo = (int)(p.vt_begin > 1 ? p.vt_begin : 1);
-    const int t_hi = (int)(p.vt_end < T ? p.vt_end : T);
-    if (p.vt_begin >= T && p.vt_begin != 0) return;             // clip finished in an earlier launch
+    const int64_t vt_begin = geo_vt_begin(p), vt_end = geo_vt_end(p);
+    if (p.ctl && p.ctl->n_sel == 0) return;                     // graph replay of a push that completed no frame
+    const int t_lo = (int)(vt_begin > 1 ? vt_begin : 1);
+    const int t_hi = (int)(vt_end < T ? vt_end : T);
+    if (vt_begin >= T && vt_begin != 0) return;                 // clip finished in an earlier launch
     double *__restrict__ vst = p.vstate + (int64_t)c * S;
     double myv = -INFINITY;
     bool observed = false;        // voiced state whose observation at the column's frame is not log(tiny)
     if (act) {
-        const int tprev = p.vt_begin == 0 ? 0 : t_lo - 1;
+        const int tprev = vt_begin == 0 ? 0 : t_lo - 1;
         const double lp = vp ? lunv[tprev] : lobs[(int64_t)tprev * os + b2c];
-        myv = p.vt_begin == 0 ? lp + p.log_pinit : vst[j];
+        myv = vt_begin == 0 ? lp + p.log_pinit : vst[j];
         observed = !vp && lp != p.log_tiny;
         store_value(0, myv);
     }
@@ -936,7 +948,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         par ^= 1;
     };
     end_of_step(myv, observed);
-    if (p.live_states != nullptr && tid == 0 && p.vt_begin == 0) p.live_states[f0] = kg;
+    if (p.live_states != nullptr && tid == 0 && vt_begin == 0) p.live_states[f0] = kg;
 
     int cur = 0;
     for (int t = t_lo; t < t_hi; ++t) {
@@ -1289,6 +1301,50 @@ void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, 
     const unsigned g = (unsigned)((F + 255) / 256);
     hipLaunchKernelGGL(rake_cols_kernel, dim3(g), dim3(256), 0, s, sdb, n_mels, F, ratio, raw);
     hipLaunchKernelGGL(rake_runs_simple_kernel, dim3(g), dim3(256), 0, s, raw, F, min_frames, max_frames, out);
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming graph helpers.  stream_advance_kernel appends the pushed samples (already on the device in
+// a fixed staging buffer) to the clip and derives the push's geometry exactly as the host path does:
+// a frame is ready when its centred 2048-sample window is complete.  stream_gather_kernel packs the
+// push's outputs into a fixed result block: [0] n_frames, then rms[8] f32, vprob[8] f64, live[8] i32.
+// ------------------------------------------------------------------------------------------
+__global__ void stream_advance_kernel(StreamCtl *ctl, const float *__restrict__ staging, int n_push,
+                                      float *__restrict__ pcm, int hop) {
+    const int64_t n0 = ctl->n_samples;
+    for (int i = threadIdx.x; i < n_push; i += blockDim.x) pcm[n0 + i] = staging[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int64_t n = n0 + n_push;
+        const int64_t ready = n >= 1024 ? (n - 1024) / hop + 1 : 0;
+        const int64_t lo = ctl->frames_done, hi = ready > lo ? ready : lo;
+        ctl->n_samples = n;
+        ctl->t_begin = lo; ctl->n_sel = hi - lo;
+        ctl->vt_begin = lo; ctl->vt_end = hi;
+        ctl->frames_done = hi;
+        ctl->meta[1] = n;            // sample_off[1]
+        ctl->meta[5] = hi - lo;      // sel_off[1]
+    }
+}
+
+__global__ void stream_gather_kernel(const StreamCtl *ctl, const float *__restrict__ rms, const double *__restrict__ vprob,
+                                     const int32_t *__restrict__ live, unsigned char *__restrict__ result) {
+    const int i = threadIdx.x;
+    int64_t *cnt = reinterpret_cast<int64_t *>(result);
+    float *r = reinterpret_cast<float *>(result + 8);
+    double *v = reinterpret_cast<double *>(result + 8 + 32);
+    int32_t *l = reinterpret_cast<int32_t *>(result + 8 + 32 + 64);
+    const int64_t n = ctl->n_sel, t0 = ctl->t_begin;
+    if (i == 0) *cnt = n;
+    if (i < 8 && i < n) { r[i] = rms[t0 + i]; v[i] = vprob[t0 + i]; l[i] = live[t0 + i]; }
+}
+
+void launch_stream_advance(StreamCtl *ctl, const float *staging, int n_push, float *pcm, int hop, hipStream_t s) {
+    hipLaunchKernelGGL(stream_advance_kernel, dim3(1), dim3(256), 0, s, ctl, staging, n_push, pcm, hop);
+}
+void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *vprob, const int32_t *live, void *result,
+                          hipStream_t s) {
+    hipLaunchKernelGGL(stream_gather_kernel, dim3(1), dim3(64), 0, s, ctl, rms, vprob, live, static_cast<unsigned char *>(result));
 }
 
 // ------------------------------------------------------------------------------------------
