@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--clips", type=int, default=64, help="clips per GPU")
     ap.add_argument("--clip-seconds", type=float, default=180.0)
-    ap.add_argument("--cpu-sample-seconds", type=float, default=60.0)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=240.0, help="oracle sample (about 15 s of CPU work)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test hook: every rank uses cuda:0 and the gloo backend (multi-rank path on a 1-GPU box)")

@@ -112,3 +112,25 @@ def test_event_packing_roundtrip(raws):
     keys = ("note", "start", "end", "velocity", "track", "technique")
     assert [[e[k] for k in keys] for e in back] == [[e[k] for k in keys] for e in ev]
     assert np.allclose([e["confidence"] for e in back], [e["confidence"] for e in ev])
+
+
+def test_randomised_frame_arrays_match_oracle():
+    """Seeded fuzz of the vectorised event logic against the oracle's literal restatement: random voicing,
+    pitch wobble, gaps, rake flags, levels and keyword settings (300 cases)."""
+    rng = np.random.default_rng(20260220)
+    eng = AegisEngine()
+    for case in range(300):
+        n = int(rng.integers(1, 400))
+        midi = np.repeat(rng.integers(40, 84, n // 7 + 1), 7)[:n] + rng.normal(0, rng.choice([0.0, 0.05, 0.3]), n)
+        f0 = 440.0 * 2 ** ((midi - 69) / 12)
+        voiced = rng.random(n) < rng.choice([0.3, 0.8, 1.0])
+        f0 = np.where(voiced, f0, 0.0)
+        raw = {"f0": f0, "voiced_flag": voiced, "voiced_probs": rng.random(n),
+               "rake_mask": rng.random(n) < 0.05, "rms": (rng.random(n) ** 3).astype(np.float32) + np.float32(1e-7)}
+        kw = {"noise_gate_db": float(rng.choice([-40, -20, -60])), "sustain_ms": float(rng.choice([0, 50, 200])),
+              "min_note_duration_ms": float(rng.choice([0, 50, 100])), "confidence_threshold": float(rng.choice([0.3, 0.7]))}
+        ref_events, ref_blob = oengine.extract_events(raw, want_smf=True, **kw)
+        buf = io.BytesIO()
+        events = eng.extract_events(raw, buf, **kw)
+        assert same_events(events, ref_events), case
+        assert buf.getvalue() == ref_blob, case
