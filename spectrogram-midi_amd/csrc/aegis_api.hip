@@ -1080,6 +1080,15 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     else if (n == "logunv") { src = h->logunv.p; count = F; }
     else if (n == "states") { src = h->states.p; count = F; esz = 4; }
     else if (n == "melpow") { src = h->melpow.p; count = F * h->tab.n_mels; esz = 4; }
+    else if (n == "cqt_cycles") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        long long v[16];
+        HIPCHK(h, hipSetDevice(h->device));
+        HIPCHK(h, hipDeviceSynchronize());
+        HIPCHK(h, cqt_debug_fetch(v));
+        if (dst && cap > 0) std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
+        return 16;
+    }
     else return AEGIS_ERR_INVALID;
     if (h->device < 0 || !src) { h->err = "stage was not run"; return AEGIS_ERR_INVALID; }
     if (dst && cap > 0) {

@@ -18,7 +18,7 @@ struct CqtBank {
     int bins_per_octave = 0;
     int half[kCqtMaxTiles] = {};          // half support of the tile, multiple of kCqtChunk, descending
     int64_t offset[kCqtMaxTiles] = {};    // float offset of the tile's fragments in `data`
-    std::vector<float> data;              // [tile][step][64 lanes] in MFMA A-operand order
+    std::vector<float> data;              // [tile][wave][pass][group][64 lanes][4 k-steps], see cqt_bank_index()
     float *dev = nullptr;
 };
 
@@ -40,5 +40,6 @@ struct CqtArgs {
 constexpr int kCqtSlideFrames = 48;
 void launch_cqt(const CqtArgs &a, const CqtBank &b, const int64_t *tile_off, int64_t n_slide_tiles, hipStream_t s);
 hipError_t cqt_configure();
+hipError_t cqt_debug_fetch(long long *dst);   // cycle counters of one workgroup (zeros unless built with CQT_ABLATE&8)
 
 }  // namespace aegis

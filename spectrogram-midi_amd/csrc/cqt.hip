@@ -12,6 +12,7 @@
 // four waves are perfectly balanced however short the outer tiles are, and the split-K partial sums are
 // reduced once at the end through LDS.  v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulate.
 #include "cqt.h"
+#include <type_traits>
 
 #include <algorithm>
 #include <cmath>
@@ -19,6 +20,9 @@
 namespace aegis {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int kPassTaps = 256;          // taps per pass (see cqt_bank_index)
+size_t cqt_bank_index(int half, int kidx, int row);
 
 const char *build_cqt_bank(CqtBank &b, int sr, int n_bins, double fmin, int bins_per_octave, double filter_scale) {
     if (n_bins < 1 || n_bins > 8 * kCqtMaxTiles) return "cqt: n_bins must be 1..128";
@@ -57,15 +61,26 @@ const char *build_cqt_bank(CqtBank &b, int sr, int n_bins, double fmin, int bins
             const int m = lo[k] + i, j = -m;                     // coefficient of y[t*hop + j] is atom[m = -j]
             const double ang = 2 * M_PI * freq[k] * m / sr;
             const double re = sc * w[i] * std::cos(ang), im = sc * w[i] * std::sin(ang);
-            const int kidx = j + b.half[T];
-            const int step = kidx >> 2, q = kidx & 3;
             for (int c = 0; c < 2; ++c) {
                 const int row = 2 * (k & 7) + c;
-                b.data[(size_t)b.offset[T] + (size_t)step * 64 + q * 16 + row] = (float)(c ? im : re);
+                b.data[(size_t)b.offset[T] + cqt_bank_index(b.half[T], j + b.half[T], row)] = (float)(c ? im : re);
             }
         }
     }
     return "";
+}
+
+// Fragment order of one tile: [wave w][pass p][group g][lane = kl*16 + row][e].  Tap kidx = j + half lies in pass
+// p = kidx / 256; inside the pass wave w owns taps [64w, 64w + 64); MFMA k-step i = 4g + e of that wave takes, on
+// k-lane kl, tap 64w + 16kl + i.  So (a) one lane's four k-steps of a group are ONE 16-byte load, (b) a wave's
+// fragments are one seamless 1-KiB-per-group stream across passes, and (c) the matching B operand -- 16
+// consecutive samples per lane and pass -- is four ds_read_b128.  Any assignment of taps to (step, k-lane) is a
+// valid GEMM as long as A and B agree; this one only fixes the float32 summation order.
+size_t cqt_bank_index(int half, int kidx, int row) {
+    const int p = kidx / kPassTaps, local = kidx % kPassTaps;
+    const int w = local / 64, kl = (local % 64) / 16, i = local % 16;
+    const size_t npass = (size_t)(2 * half / kPassTaps);
+    return (((size_t)w * npass + p) * 4 + i / 4) * 256 + (size_t)(kl * 16 + row) * 4 + i % 4;
 }
 
 struct CqtMeta {
@@ -80,9 +95,12 @@ __device__ __forceinline__ int clip_of(const int64_t *__restrict__ off, int n, i
     return lo;
 }
 
-constexpr int kPass = 256;              // samples of every frame staged per pass (one per thread and column)
-constexpr int kBst = kPass + 2;         // padded row of the staging tile: B fragments hit 64 distinct banks
+constexpr int kPass = kPassTaps;        // samples of every frame staged per pass (one per thread and column)
+constexpr int kBst = kPass + 1;         // padded row of the staging tile: 16 columns x 4 k-lanes (16 apart) hit 64 distinct banks
 constexpr int kCqtRowTiles = 11;        // register accumulators are sized for 84 bins; more bins loop in groups
+#ifndef CQT_ABLATE
+#define CQT_ABLATE 0
+#endif
 constexpr int kGroup = 4;               // k-steps whose A fragments are fetched ahead together
 
 template <int NT>
@@ -145,32 +163,32 @@ __global__ __launch_bounds__(256) void cqt_kernel(CqtArgs a, CqtMeta m, const fl
         int na = 0;
 #pragma unroll
         for (int T = 0; T < NT; ++T) na += (tile0 + T < m.n_tiles && m.half[tile0 + T] > reach_j) ? 1 : 0;
-        // this wave's k-steps of the pass: s = w, w+4, ...; A fragments fetched one group of steps ahead
+        // this wave's taps of the pass are [64w, 64w+64): k-step i on k-lane kl takes tap 64w + 16kl + i
+        // (cqt_bank_index); the four A fragments of a group are one 16-byte load, fetched one group ahead
         constexpr int kSteps = kPass / 4 / 4;            // steps per wave and pass
-        float an[NT][kGroup];
-        auto load_a = [&](int g, float (&dst)[NT][kGroup]) {
+        f32x4 an[NT];
+        auto load_a = [&](int g, f32x4 (&dst)[NT]) {
 #pragma unroll
             for (int T = 0; T < NT; ++T)
                 if (T < na) {
-                    const int64_t base = m.offset[tile0 + T] + ((int64_t)(p * kPass + m.half[tile0 + T]) / 4) * 64 + lane;
-#pragma unroll
-                    for (int i = 0; i < kGroup; ++i) dst[T][i] = bank[base + (int64_t)(w + 4 * (g * kGroup + i)) * 64];
+                    const int hT = m.half[tile0 + T];
+                    const int64_t npT = 2 * hT / kPass, pT = (p * kPass + hT) / kPass;
+                    const int64_t base = m.offset[tile0 + T] + ((w * npT + pT) * 4 + g) * 256 + lane * 4;
+                    dst[T] = *reinterpret_cast<const f32x4 *>(bank + base);
                 }
         };
         load_a(0, an);
         for (int g = 0; g < kSteps / kGroup; ++g) {
-            float ac[NT][kGroup];
+            f32x4 ac[NT];
 #pragma unroll
-            for (int T = 0; T < NT; ++T)
-#pragma unroll
-                for (int i = 0; i < kGroup; ++i) ac[T][i] = an[T][i];
+            for (int T = 0; T < NT; ++T) ac[T] = an[T];
             if (g + 1 < kSteps / kGroup) load_a(g + 1, an);
 #pragma unroll
             for (int i = 0; i < kGroup; ++i) {
-                const int s = w + 4 * (g * kGroup + i);
                 float b[4];
 #pragma unroll
-                for (int ct = 0; ct < 4; ++ct) b[ct] = B[(ct * 16 + (lane & 15)) * kBst + 4 * s + (lane >> 4)];
+                for (int ct = 0; ct < 4; ++ct)
+                    b[ct] = B[(ct * 16 + (lane & 15)) * kBst + 64 * w + 16 * (lane >> 4) + g * kGroup + i];
 #pragma unroll
                 for (int T = 0; T < NT; ++T)
                     if (T < na) {
@@ -212,25 +230,43 @@ __global__ __launch_bounds__(256) void cqt_kernel(CqtArgs a, CqtMeta m, const fl
 }
 
 // ------------------------------------------------------------------------------------------
-// Sliding-window variant (hop <= 680): the 48 frames of a workgroup are hop-shifted views of ONE
-// stretch of signal, so LDS holds that stretch as a ring in sample space (32 768 floats + bank
-// padding) and a pass of 256 taps needs only 256 NEW samples -- one per thread -- instead of
+// Sliding-window variant (hop <= 512, hop % 16 == 0): the 48 frames of a workgroup are hop-shifted
+// views of ONE stretch of signal, so LDS holds that stretch as a ring in sample space (32 768 floats
+// + bank padding) and a pass of 256 taps needs only 256 NEW samples -- one per thread -- instead of
 // re-staging 256 samples for every frame.  Workgroups are cut per clip so a tile never spans two
-// signals.  B fragment (col, k) = ring[col*hop + pass*256 + k]; with hop = 512 the +2 floats per
-// 512 keep the 16 columns x 4 k-lanes on 64 distinct banks.
+// signals.  The B operand of lane (col, kl) in pass q is the 16 consecutive samples
+// ring[col*hop + q*256 + 64w + 16kl + (0..15)]: four ds_read_b128; with hop = 512 the 4 floats of
+// padding per 512 samples put the 16 columns on 16 distinct 16-byte bank groups.
+//
+// What bounds it (profiles/README.md): every workgroup streams the whole bank (4.4 MB for CQT-84) from
+// L2 through ONE wave per SIMD.  With one dword per lane per k-step the vector-memory pipe (~1 load per
+// 20-40 cycles per CU) and 250 cycles of address/branch work per k-step, not the MFMAs, set the pace
+// (27 % of the f32 MFMA peak); hence 16-byte A loads, 16-byte B reads, per-tile register queues whose
+// depth follows the time a k-step lasts, and one taken branch per group.
 // ------------------------------------------------------------------------------------------
 constexpr int kRing = 32768;
-constexpr int kSlideFrames = 48;
+constexpr int kRingPad = 4;                                     // floats of padding per 512 samples
+constexpr int kRingFloats = kRing + kRingPad * (kRing / 512);
+constexpr int kSlideFrames = kCqtSlideFrames;
 __device__ __forceinline__ int ring_idx(int u) {
     const int x = u & (kRing - 1);
-    return x + 2 * (x >> 9);
+    return x + kRingPad * (x >> 9);
 }
+// Groups (of 4 k-steps) that tile T's A fragments are fetched ahead of their MFMAs.  Tile T is only ever active
+// together with tiles 0..T-1, so a group lasts >= (T+1) x 12 MFMAs = (T+1) x 384 cycles: the longest filters run
+// alone in the outer passes and need the deepest queue.  Must divide the 4 groups of a pass.
+__host__ __device__ constexpr int slide_lookahead(int T) { return T == 0 ? 4 : T <= 3 ? 2 : 1; }
+
+#if CQT_ABLATE & 8
+__device__ long long g_cqt_dbg[16];
+#endif
 
 template <int NT>
 __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, const float *__restrict__ bank, int tile0,
                                                         const int64_t *__restrict__ tile_off) {
-    extern __shared__ __align__(16) float ring[];        // kRing + 2*64 floats
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    extern __shared__ __align__(16) float ring[];        // kRingFloats
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: keeps the bank offsets in SGPRs
     const int c = clip_of(tile_off, a.n_clips, (int64_t)blockIdx.x);
     const int64_t t0 = ((int64_t)blockIdx.x - tile_off[c]) * kSlideFrames;
     const int64_t Fc = a.frame_off[c + 1] - a.frame_off[c];
@@ -241,72 +277,162 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
     const int64_t base = t0 * hop - half0;               // absolute sample of ring coordinate u = 0
     const int span = (kSlideFrames - 1) * hop + kPass;   // samples one pass touches
 
+#if CQT_ABLATE & 8
+    long long tk0 = clock64(), tk_bar = 0; long long tk_na[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     f32x4 acc[NT][3];
 #pragma unroll
     for (int T = 0; T < NT; ++T)
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) acc[T][ct] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    int colb[3];                                         // ring coordinate of (column, k-lane) at pass 0, step 0
+    int colb[3];                                         // ring coordinate of (column, k-lane, wave) at pass 0, step 0
 #pragma unroll
-    for (int ct = 0; ct < 3; ++ct) colb[ct] = (ct * 16 + (lane & 15)) * hop + (lane >> 4);
+    for (int ct = 0; ct < 3; ++ct) colb[ct] = (ct * 16 + (lane & 15)) * hop + 16 * (lane >> 4) + 64 * w;
 
+#pragma unroll 8
     for (int u = tid; u < span; u += 256) {              // window of the first pass
         const int64_t sidx = base + u;
         ring[ring_idx(u)] = (sidx >= 0 && sidx < n) ? y[sidx] : 0.0f;
     }
     __syncthreads();
     const int npass = 2 * half0 / kPass;
-    for (int q = 0; q < npass; ++q) {
-        // the 256 samples that enter the window with the next pass (in flight under the MFMAs)
-        const int un = span + q * kPass + tid;
-        const int64_t sn = base + un;
-        const float fresh = (q + 1 < npass && sn >= 0 && sn < n) ? y[sn] : 0.0f;
-        // tiles whose support reaches this pass: j in [q*256 - half0, +256)
+    constexpr int kGroups = kPass / 4 / 16;              // groups of 4 k-steps (16 taps) per wave and pass (= 4)
+    // Row tiles are ordered longest filter first, so the tiles whose support reaches pass q are a prefix
+    // [0, na(q)): the per-tile work is a chain of nested ifs that is left at the first inactive tile (ONE
+    // taken branch per group).  The A fragments are register queues refilled IN PLACE: the slot a group has
+    // just consumed is loaded with the group slide_lookahead(T) further down the wave's stream, which
+    // continues seamlessly into the next pass.
+    auto active_tiles = [&](int q) {                     // pass q covers j in [q*256 - half0, +256)
         const int j0 = q * kPass - half0;
         const int reach_j = j0 >= 0 ? j0 : -(j0 + kPass);
         int na = 0;
 #pragma unroll
         for (int T = 0; T < NT; ++T) na += (tile0 + T < m.n_tiles && m.half[tile0 + T] > reach_j) ? 1 : 0;
-        constexpr int kSteps = kPass / 4 / 4;
-        float an[NT][kGroup];
-        auto load_a = [&](int g, float (&dst)[NT][kGroup]) {
+        return na;
+    };
+    // byte offset of (tile T, this wave, group 0 of pass 0) in the bank; below the tile's data until it is active
+    int tb[NT];
 #pragma unroll
-            for (int T = 0; T < NT; ++T)
-                if (T < na) {
-                    const int64_t b0 = m.offset[tile0 + T] + ((int64_t)(j0 + m.half[tile0 + T]) / 4) * 64 + lane;
+    for (int T = 0; T < NT; ++T) {
+        const int hT = tile0 + T < m.n_tiles ? m.half[tile0 + T] : half0;
+        tb[T] = tile0 + T < m.n_tiles
+                    ? (int)(m.offset[tile0 + T] * 4) + (w * (2 * hT / kPass) - (half0 - hT) / kPass) * (kGroups * 1024) : 0;
+    }
+    const char *__restrict__ bank_b = reinterpret_cast<const char *>(bank);
+    auto frag = [&](int T, int G) {                      // G = pass * 4 + group, counted from pass 0 of tile tile0
+#if CQT_ABLATE & 1
+        const float v = __int_as_float((lane + T + G) | 0x3f000000);
+        return f32x4{v, v, v, v};
+#else
+        const uint32_t off = (uint32_t)(tb[T] + G * 1024) + (uint32_t)lane * 16u;
+        return *reinterpret_cast<const f32x4 *>(bank_b + off);
+#endif
+    };
+    f32x4 slot[NT][kGroups];                             // tile T uses the first slide_lookahead(T) entries
+    int na_next = active_tiles(0);
+    {                                                    // queues of the tiles active in pass 0
+        auto fill0 = [&](auto self, auto tc) -> void {
+            constexpr int T = decltype(tc)::value;
+            if constexpr (T < NT) {
+                if (T < na_next) {
 #pragma unroll
-                    for (int i = 0; i < kGroup; ++i) dst[T][i] = bank[b0 + (int64_t)(w + 4 * (g * kGroup + i)) * 64];
+                    for (int gi = 0; gi < slide_lookahead(T); ++gi) slot[T][gi] = frag(T, gi);
+                    self(self, std::integral_constant<int, T + 1>{});
                 }
-        };
-        load_a(0, an);
-        for (int g = 0; g < kSteps / kGroup; ++g) {
-            float ac[NT][kGroup];
-#pragma unroll
-            for (int T = 0; T < NT; ++T)
-#pragma unroll
-                for (int i = 0; i < kGroup; ++i) ac[T][i] = an[T][i];
-            if (g + 1 < kSteps / kGroup) load_a(g + 1, an);
-#pragma unroll
-            for (int i = 0; i < kGroup; ++i) {
-                const int s = w + 4 * (g * kGroup + i);
-                float b[3];
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
-                    b[ct] = ring[ring_idx(colb[ct] + q * kPass + 4 * s)];
-#pragma unroll
-                for (int T = 0; T < NT; ++T)
-                    if (T < na) {
-#pragma unroll
-                        for (int ct = 0; ct < 3; ++ct)
-                            acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[T][i], b[ct], acc[T][ct], 0, 0, 0);
-                    }
             }
+        };
+        fill0(fill0, std::integral_constant<int, 0>{});
+    }
+#if CQT_ABLATE & 8
+    long long tk1 = clock64();
+#endif
+    for (int q = 0; q < npass; ++q) {
+#if CQT_ABLATE & 8
+        long long tp0 = clock64();
+#endif
+        // the 256 samples that enter the window with the next pass (in flight under the MFMAs)
+        const int un = span + q * kPass + tid;
+        const int64_t sn = base + un;
+        const float fresh = (q + 1 < npass && sn >= 0 && sn < n) ? y[sn] : 0.0f;
+        const int na = na_next;
+        na_next = q + 1 < npass ? active_tiles(q + 1) : 0;
+        const int ncont = na_next < na ? na_next : na;   // tiles whose queue keeps running into the next pass
+        int rb[3];                                       // opaque per pass: stops LICM from hoisting per-pass addresses
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            rb[ct] = ring_idx(colb[ct] + q * kPass);
+            asm volatile("" : "+v"(rb[ct]));
         }
+        auto read_b = [&](int ct, int g) {
+#if CQT_ABLATE & 2
+            const float v = __int_as_float(((rb[ct] + g) & 0xffff) | 0x3f000000);
+            return f32x4{v, v, v, v};
+#else
+            return *reinterpret_cast<const f32x4 *>(ring + rb[ct] + 4 * g);   // 16 samples never straddle a pad
+#endif
+        };
+        {                                                // tiles that join in the next pass: start their queues now
+            auto fill = [&](auto self, auto tc) -> void {
+                constexpr int T = decltype(tc)::value;
+                if constexpr (T < NT) {
+                    if (T < na_next) {
+                        if (T >= na) {
+#pragma unroll
+                            for (int gi = 0; gi < slide_lookahead(T); ++gi) slot[T][gi] = frag(T, (q + 1) * kGroups + gi);
+                        }
+                        self(self, std::integral_constant<int, T + 1>{});
+                    }
+                }
+            };
+            if (na_next > na) fill(fill, std::integral_constant<int, 0>{});
+        }
+        f32x4 bn[3];                                     // B fragments are read one group ahead as well
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) bn[ct] = read_b(ct, 0);
+#pragma unroll
+        for (int g = 0; g < kGroups; ++g) {
+            f32x4 b[3];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) b[ct] = bn[ct];
+            if (g + 1 < kGroups) {
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) bn[ct] = read_b(ct, g + 1);
+            }
+            auto tiles = [&](auto self, auto tc) -> void {
+                constexpr int T = decltype(tc)::value;
+                if constexpr (T < NT) {
+                    if (T < na) {
+                        constexpr int LA = slide_lookahead(T);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int ct = 0; ct < 3; ++ct)
+                                acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[T][g % LA][e], b[ct][e], acc[T][ct], 0, 0, 0);
+                        if (g + LA < kGroups || T < ncont) slot[T][g % LA] = frag(T, q * kGroups + g + LA);
+                        self(self, std::integral_constant<int, T + 1>{});
+                    }
+                }
+            };
+            tiles(tiles, std::integral_constant<int, 0>{});
+        }
+#if CQT_ABLATE & 8
+        long long tp1 = clock64();
+#endif
+#if !(CQT_ABLATE & 4)
         ring[ring_idx(un)] = fresh;      // lands >= 8 192 slots away from anything the current pass reads
         __syncthreads();
+#endif
+#if CQT_ABLATE & 8
+        { long long tp2 = clock64(); tk_bar += tp2 - tp1;
+#pragma unroll
+          for (int k = 1; k < 12; ++k) if (na == k) tk_na[k] += tp1 - tp0; }
+#endif
     }
 
+#if CQT_ABLATE & 8
+    long long tk2 = clock64();
+#endif
     // ---- split-K reduction over the 4 waves and magnitudes, one row tile at a time ----------------
     float *red = ring;                                   // [4 waves][3 ct][4 regs][64 lanes]
 #pragma unroll
@@ -332,14 +458,28 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
         }
         __syncthreads();
     }
+#if CQT_ABLATE & 8
+    if (blockIdx.x == 1000 && tid == 0) {
+        long long tk3 = clock64();
+        g_cqt_dbg[0] = tk1 - tk0;
+        for (int k = 1; k < 12; ++k) g_cqt_dbg[k] = tk_na[k];
+        g_cqt_dbg[12] = tk_bar; g_cqt_dbg[13] = tk3 - tk2; g_cqt_dbg[14] = tk3 - tk0;
+    }
+#endif
 }
+
+#if CQT_ABLATE & 8
+hipError_t cqt_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_cqt_dbg), sizeof(long long) * 16); }
+#else
+hipError_t cqt_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
+#endif
 
 hipError_t cqt_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cqt_kernel<kCqtRowTiles>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * kCqtFrames * kBst * sizeof(float)));
     if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(cqt_slide_kernel<kCqtRowTiles>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)((kRing + 128) * sizeof(float)));
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(kRingFloats * sizeof(float)));
 }
 
 void launch_cqt(const CqtArgs &a, const CqtBank &b, const int64_t *tile_off, int64_t n_slide_tiles, hipStream_t s) {
@@ -347,10 +487,10 @@ void launch_cqt(const CqtArgs &a, const CqtBank &b, const int64_t *tile_off, int
     CqtMeta m{};
     m.n_bins = b.n_bins; m.n_tiles = b.n_tiles;
     for (int T = 0; T < b.n_tiles; ++T) { m.half[T] = b.half[T]; m.offset[T] = b.offset[T]; }
-    if (tile_off != nullptr && n_slide_tiles > 0 && (kSlideFrames - 1) * a.hop + 2 * kPass <= kRing - 8192) {
+    if (tile_off != nullptr && n_slide_tiles > 0 && a.hop % 16 == 0 && (kSlideFrames - 1) * a.hop + 2 * kPass <= kRing - 8192) {
         for (int tile0 = 0; tile0 < b.n_tiles; tile0 += kCqtRowTiles)
             hipLaunchKernelGGL(cqt_slide_kernel<kCqtRowTiles>, dim3((unsigned)n_slide_tiles), dim3(256),
-                               (kRing + 128) * sizeof(float), s, a, m, b.dev, tile0, tile_off);
+                               kRingFloats * sizeof(float), s, a, m, b.dev, tile0, tile_off);
         return;
     }
     const size_t lds = (size_t)2 * kCqtFrames * kBst * sizeof(float);

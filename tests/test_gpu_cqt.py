@@ -41,3 +41,15 @@ def test_other_banks():
     with pytest.raises(_lib.AegisError):
         h.cqt([y], n_bins=84, fmin=4000.0)                               # top bins above Nyquist
     h.close()
+
+
+def test_other_hops():
+    """hop 256 stays on the sliding-window kernel; hop 1024 (window too wide for the LDS ring) and hop 441
+    (not a multiple of 16) take the per-frame staging kernel.  Same bank, same answer."""
+    y = signals.polyphonic_clip(2.5, seed=101)
+    for hop in (256, 1024, 441):
+        h = _lib.Handle(hop_length=hop, scipy_tables=False)
+        got = h.cqt([y, y[:30000]])
+        check(got[0], y, hop_length=hop)
+        check(got[1], y[:30000], hop_length=hop)
+        h.close()
