@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
     const int hop = a.hop;
     const int half0 = m.half[tile0];
     const int64_t base = t0 * hop - half0;               // absolute sample of ring coordinate u = 0
-    const int span = (kSlideFrames - 1) * hop + kPass;   // samples one pass touches
+    const int span = (kSlideFrames - 1) * hop + 2 * kPass;   // samples a pair of passes touches
 
 #if CQT_ABLATE & 8
     long long tk0 = clock64(), tk_bar = 0; long long tk_na[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -290,10 +290,16 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
 #pragma unroll
     for (int ct = 0; ct < 3; ++ct) colb[ct] = (ct * 16 + (lane & 15)) * hop + 16 * (lane >> 4) + 64 * w;
 
+    if (n > 0) {                                         // window of the first pair; clamped, branch-free loads batch
 #pragma unroll 8
-    for (int u = tid; u < span; u += 256) {              // window of the first pass
-        const int64_t sidx = base + u;
-        ring[ring_idx(u)] = (sidx >= 0 && sidx < n) ? y[sidx] : 0.0f;
+        for (int u = tid; u < span; u += 256) {
+            const int64_t sidx = base + u;
+            const int64_t cl = sidx < 0 ? 0 : sidx >= n ? n - 1 : sidx;
+            const float v = y[cl];
+            ring[ring_idx(u)] = cl == sidx ? v : 0.0f;
+        }
+    } else {
+        for (int u = tid; u < span; u += 256) ring[ring_idx(u)] = 0.0f;
     }
     __syncthreads();
     const int npass = 2 * half0 / kPass;
@@ -303,22 +309,25 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
     // taken branch per group).  The A fragments are register queues refilled IN PLACE: the slot a group has
     // just consumed is loaded with the group slide_lookahead(T) further down the wave's stream, which
     // continues seamlessly into the next pass.
-    auto active_tiles = [&](int q) {                     // pass q covers j in [q*256 - half0, +256)
-        const int j0 = q * kPass - half0;
-        const int reach_j = j0 >= 0 ? j0 : -(j0 + kPass);
-        int na = 0;
-#pragma unroll
-        for (int T = 0; T < NT; ++T) na += (tile0 + T < m.n_tiles && m.half[tile0 + T] > reach_j) ? 1 : 0;
-        return na;
-    };
+    // tile T is active in passes [first[T], npass - first[T]) (supports are centred); kept in SGPRs so that the
+    // per-pass count is a dozen scalar compares instead of a chain of kernarg loads
+    int first[NT];
     // byte offset of (tile T, this wave, group 0 of pass 0) in the bank; below the tile's data until it is active
     int tb[NT];
 #pragma unroll
     for (int T = 0; T < NT; ++T) {
-        const int hT = tile0 + T < m.n_tiles ? m.half[tile0 + T] : half0;
-        tb[T] = tile0 + T < m.n_tiles
-                    ? (int)(m.offset[tile0 + T] * 4) + (w * (2 * hT / kPass) - (half0 - hT) / kPass) * (kGroups * 1024) : 0;
+        const bool present = tile0 + T < m.n_tiles;
+        const int hT = present ? m.half[tile0 + T] : half0;
+        first[T] = present ? (half0 - hT) / kPass : 0x3fffffff;
+        tb[T] = present ? (int)(m.offset[tile0 + T] * 4) + (w * (2 * hT / kPass) - (half0 - hT) / kPass) * (kGroups * 1024) : 0;
     }
+    auto active_tiles = [&](int q) {
+        const int d = q < npass - 1 - q ? q : npass - 1 - q;
+        int na = 0;
+#pragma unroll
+        for (int T = 0; T < NT; ++T) na += first[T] <= d ? 1 : 0;
+        return na;
+    };
     const char *__restrict__ bank_b = reinterpret_cast<const char *>(bank);
     auto frag = [&](int T, int G) {                      // G = pass * 4 + group, counted from pass 0 of tile tile0
 #if CQT_ABLATE & 1
@@ -344,42 +353,39 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
         };
         fill0(fill0, std::integral_constant<int, 0>{});
     }
+    // Passes run in PAIRS between barriers: supports are multiples of 512 taps, so both passes of a pair see the
+    // same active tiles; one tile count, one barrier and one 512-sample refill of the ring per 512 taps.
+    float fresh_next[2];                                 // the 512 samples that enter the window with the next pair
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int64_t sn = base + span + k * 256 + tid;
+        fresh_next[k] = (2 < npass && sn >= 0 && sn < n) ? y[sn] : 0.0f;
+    }
 #if CQT_ABLATE & 8
     long long tk1 = clock64();
 #endif
-    for (int q = 0; q < npass; ++q) {
+    for (int q2 = 0; q2 < npass; q2 += 2) {
 #if CQT_ABLATE & 8
         long long tp0 = clock64();
 #endif
-        // the 256 samples that enter the window with the next pass (in flight under the MFMAs)
-        const int un = span + q * kPass + tid;
-        const int64_t sn = base + un;
-        const float fresh = (q + 1 < npass && sn >= 0 && sn < n) ? y[sn] : 0.0f;
-        const int na = na_next;
-        na_next = q + 1 < npass ? active_tiles(q + 1) : 0;
-        const int ncont = na_next < na ? na_next : na;   // tiles whose queue keeps running into the next pass
-        int rb[3];                                       // opaque per pass: stops LICM from hoisting per-pass addresses
+        const int un = span + q2 * kPass + tid;
+        const float fresh[2] = {fresh_next[0], fresh_next[1]};      // fetched during the previous pair
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) {
-            rb[ct] = ring_idx(colb[ct] + q * kPass);
-            asm volatile("" : "+v"(rb[ct]));
+        for (int k = 0; k < 2; ++k) {
+            const int64_t sn = base + un + 2 * kPass + k * 256;
+            fresh_next[k] = (q2 + 4 < npass && sn >= 0 && sn < n) ? y[sn] : 0.0f;
         }
-        auto read_b = [&](int ct, int g) {
-#if CQT_ABLATE & 2
-            const float v = __int_as_float(((rb[ct] + g) & 0xffff) | 0x3f000000);
-            return f32x4{v, v, v, v};
-#else
-            return *reinterpret_cast<const f32x4 *>(ring + rb[ct] + 4 * g);   // 16 samples never straddle a pad
-#endif
-        };
-        {                                                // tiles that join in the next pass: start their queues now
+        const int na = na_next;
+        na_next = q2 + 2 < npass ? active_tiles(q2 + 2) : 0;
+        const int ncont = na_next < na ? na_next : na;   // tiles whose queue keeps running into the next pair
+        {                                                // tiles that join in the next pair: start their queues now
             auto fill = [&](auto self, auto tc) -> void {
                 constexpr int T = decltype(tc)::value;
                 if constexpr (T < NT) {
                     if (T < na_next) {
                         if (T >= na) {
 #pragma unroll
-                            for (int gi = 0; gi < slide_lookahead(T); ++gi) slot[T][gi] = frag(T, (q + 1) * kGroups + gi);
+                            for (int gi = 0; gi < slide_lookahead(T); ++gi) slot[T][gi] = frag(T, (q2 + 2) * kGroups + gi);
                         }
                         self(self, std::integral_constant<int, T + 1>{});
                     }
@@ -387,40 +393,60 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
             };
             if (na_next > na) fill(fill, std::integral_constant<int, 0>{});
         }
-        f32x4 bn[3];                                     // B fragments are read one group ahead as well
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct) bn[ct] = read_b(ct, 0);
+        for (int hp = 0; hp < 2; ++hp) {
+            const int q = q2 + hp;
+            int rb[3];                                   // opaque per pass: stops LICM from hoisting per-pass addresses
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-            f32x4 b[3];
-#pragma unroll
-            for (int ct = 0; ct < 3; ++ct) b[ct] = bn[ct];
-            if (g + 1 < kGroups) {
-#pragma unroll
-                for (int ct = 0; ct < 3; ++ct) bn[ct] = read_b(ct, g + 1);
+            for (int ct = 0; ct < 3; ++ct) {
+                rb[ct] = ring_idx(colb[ct] + q * kPass) >> 2;    // in 16-byte units: 16 samples never straddle a pad
+                asm volatile("" : "+v"(rb[ct]));
             }
-            auto tiles = [&](auto self, auto tc) -> void {
-                constexpr int T = decltype(tc)::value;
-                if constexpr (T < NT) {
-                    if (T < na) {
-                        constexpr int LA = slide_lookahead(T);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int ct = 0; ct < 3; ++ct)
-                                acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[T][g % LA][e], b[ct][e], acc[T][ct], 0, 0, 0);
-                        if (g + LA < kGroups || T < ncont) slot[T][g % LA] = frag(T, q * kGroups + g + LA);
-                        self(self, std::integral_constant<int, T + 1>{});
-                    }
-                }
+            auto read_b = [&](int ct, int g) {
+#if CQT_ABLATE & 2
+                const float v = __int_as_float(((rb[ct] + g) & 0xffff) | 0x3f000000);
+                return f32x4{v, v, v, v};
+#else
+                return reinterpret_cast<const f32x4 *>(ring)[rb[ct] + g];
+#endif
             };
-            tiles(tiles, std::integral_constant<int, 0>{});
+            f32x4 bn[3];                                 // B fragments are read one group ahead as well
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) bn[ct] = read_b(ct, 0);
+#pragma unroll
+            for (int g = 0; g < kGroups; ++g) {
+                f32x4 b[3];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct) b[ct] = bn[ct];
+                if (g + 1 < kGroups) {
+#pragma unroll
+                    for (int ct = 0; ct < 3; ++ct) bn[ct] = read_b(ct, g + 1);
+                }
+                auto tiles = [&](auto self, auto tc) -> void {
+                    constexpr int T = decltype(tc)::value;
+                    if constexpr (T < NT) {
+                        if (T < na) {
+                            constexpr int LA = slide_lookahead(T);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                for (int ct = 0; ct < 3; ++ct)
+                                    acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[T][g % LA][e], b[ct][e], acc[T][ct], 0, 0, 0);
+                            if (g + LA < kGroups || hp == 0 || T < ncont) slot[T][g % LA] = frag(T, q * kGroups + g + LA);
+                            self(self, std::integral_constant<int, T + 1>{});
+                        }
+                    }
+                };
+                tiles(tiles, std::integral_constant<int, 0>{});
+            }
         }
 #if CQT_ABLATE & 8
         long long tp1 = clock64();
 #endif
 #if !(CQT_ABLATE & 4)
-        ring[ring_idx(un)] = fresh;      // lands >= 8 192 slots away from anything the current pass reads
+        // lands >= 7 680 slots away from anything the current pair reads (launch_cqt checks the window size)
+        ring[ring_idx(un)] = fresh[0];
+        ring[ring_idx(un + 256)] = fresh[1];
         __syncthreads();
 #endif
 #if CQT_ABLATE & 8
@@ -487,7 +513,7 @@ void launch_cqt(const CqtArgs &a, const CqtBank &b, const int64_t *tile_off, int
     CqtMeta m{};
     m.n_bins = b.n_bins; m.n_tiles = b.n_tiles;
     for (int T = 0; T < b.n_tiles; ++T) { m.half[T] = b.half[T]; m.offset[T] = b.offset[T]; }
-    if (tile_off != nullptr && n_slide_tiles > 0 && a.hop % 16 == 0 && (kSlideFrames - 1) * a.hop + 2 * kPass <= kRing - 8192) {
+    if (tile_off != nullptr && n_slide_tiles > 0 && a.hop % 16 == 0 && (kSlideFrames - 1) * a.hop + 4 * kPass <= kRing - 7168) {
         for (int tile0 = 0; tile0 < b.n_tiles; tile0 += kCqtRowTiles)
             hipLaunchKernelGGL(cqt_slide_kernel<kCqtRowTiles>, dim3((unsigned)n_slide_tiles), dim3(256),
                                kRingFloats * sizeof(float), s, a, m, b.dev, tile0, tile_off);

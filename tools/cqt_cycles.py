@@ -5,7 +5,7 @@ from spectrogram_midi_amd import _lib, signals
 clips = [signals.polyphonic_clip(30.0, seed=100 + i % 4) for i in range(64)]
 h = _lib.Handle(); h.cqt(clips[:2]); h.cqt(clips)
 v = h.debug_fetch("cqt_cycles")
-passes = {1: 32, 2: 22, 3: 14, 4: 8, 5: 4, 6: 4, 7: 4, 11: 4}
+passes = {1: 32, 2: 22, 3: 14, 4: 8, 5: 4, 6: 4, 7: 4, 11: 4}     # 256-tap passes per active-tile count (CQT-84)
 print("prologue", int(v[0]), "barrier", int(v[12]), "epilogue", int(v[13]), "total", int(v[14]))
 for k in range(1, 12):
     if v[k]:
