@@ -1080,6 +1080,28 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     else if (n == "logunv") { src = h->logunv.p; count = F; }
     else if (n == "states") { src = h->states.p; count = F; esz = 4; }
     else if (n == "melpow") { src = h->melpow.p; count = F * h->tab.n_mels; esz = 4; }
+    else if (n == "frame_cycles") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {
+            long long v[16];
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, frame_debug_fetch(v));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
+        }
+        return 16;
+    }
+    else if (n == "viterbi_cycles") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {                     // reading resets the counters
+            long long v[128];
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, viterbi_debug_fetch(v, true));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 128) * 8);
+        }
+        return 128;
+    }
     else if (n == "cqt_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;
         long long v[16];

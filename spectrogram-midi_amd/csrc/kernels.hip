@@ -118,7 +118,16 @@ __device__ __forceinline__ void fft2048(double2 *a, double2 *b, const double2 *_
 //   * |XW|^2 rounded through complex64 like librosa.stft -> Slaney mel -> clip max
 // 1.5 FFTs per frame instead of 3.
 // ------------------------------------------------------------------------------------------
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+__device__ long long g_frm_dbg[16];
+#define FRM_TICK(k) { const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
+#else
+#define FRM_TICK(k)
+#endif
 __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables tb) {
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+    long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = clock64();
+#endif
     extern __shared__ __align__(16) unsigned char fsm[];
     double2 *bufs = reinterpret_cast<double2 *>(fsm);            // [2 halves][2][2048]
     float *xs_all = reinterpret_cast<float *>(bufs + 4 * 2048);  // [2][2048]
@@ -150,6 +159,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     }
     if (lt == 0) smax_all[hh] = 0u;
     __syncthreads();
+    FRM_TICK(0)
 
     // ---- feature.rms: np.mean(np.square(x), axis=-2) then sqrt, float32 ----------------------
     const bool want_rms = (p.stages & 0x8u) && p.out_rms != nullptr;
@@ -178,6 +188,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
         }
     }
     if (!(p.stages & 0x7u)) return;
+    FRM_TICK(1)
 
     // ---- packed forward FFT of (frame, reversed first half) ---------------------------------
 #pragma unroll
@@ -187,6 +198,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     }
     __syncthreads();
     fft2048<256>(bufA, bufB, tb.twiddle, lt);
+    FRM_TICK(2)
 
     // A[k] -> bufB[k] (k <= 1024); P[k] = A[k]*B[k] kept in registers
     double2 P[5];
@@ -223,6 +235,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     }
     __syncthreads();
 
+    FRM_TICK(3)
     // ---- mel projection (each half: its own frame) -------------------------------------------
     if (p.stages & 0x3u) {
         if (lt < p.n_mels && live) {
@@ -234,6 +247,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
             atomicMax(&smax_all[hh], __float_as_uint(acc));
         }
     }
+    FRM_TICK(4)
     // ---- one inverse FFT for both frames -------------------------------------------------------
     if (p.stages & 0x4u) {
         // conj(Q), Q = Hermitian extension of P0 + i*P1, built by all 512 threads into bufs[0].B
@@ -246,6 +260,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
         }
         __syncthreads();
         fft2048<512>(q, q2, tb.twiddle, tid);
+        FRM_TICK(5)
         // FFT(conj Q) = N * conj(acf0 + i acf1)
         if (live) {
             double *acf = p.acf + f * (int64_t)p.lag_stride;
@@ -258,7 +273,16 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
         __syncthreads();
     }
     if ((p.stages & 0x3u) && lt == 0 && live) atomicMax(&p.clipmax[c], smax_all[hh]);
+    FRM_TICK(6)
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+    if (blockIdx.x == 5000 && tid == 0) { for (int k = 0; k < 7; ++k) g_frm_dbg[k] = facc[k]; }
+#endif
 }
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+hipError_t frame_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_frm_dbg), sizeof(long long) * 16); }
+#else
+hipError_t frame_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Kernel 2: one frame per lane.  Everything here is sequential along the lag axis in the
@@ -828,6 +852,13 @@ struct BandLT {
     double lmax[4];           // [v*2+v'] largest log-transition of that block over ALL row classes
 };
 
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
+__device__ long long g_vit_dbg[16 * 8];
+#define VIT_TICK(k) { const long long now__ = clock64(); tacc[k] += now__ - tlast; tlast = now__; }
+#else
+#define VIT_TICK(k)
+#endif
+
 template <int H, bool LT_LDS>
 __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTables tb, BandLT<H> blt) {
     constexpr int W = 2 * H + 1;
@@ -908,6 +939,17 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         observed = !vp && lp != p.log_tiny;
         store_value(0, myv);
     }
+    // Back-pointer chunk maps are composed on the fly: org[s] = state at the start of the current 16-step chunk
+    // of the best path into s (one dependent LDS gather per step, double buffered), stored as the chunk map when
+    // the chunk closes.  A launch that starts inside a chunk (streaming) rebuilds org from the HBM pointers.
+    uint16_t *org = ring;      // [2][S]
+    int oc = 0;
+    if (act) {
+        const int tp = t_lo - 1, c0 = (tp / C) * C;
+        int s0 = j;
+        for (int tt = tp; tt > c0; --tt) s0 = ptr[(int64_t)tt * S + s0];
+        org[j] = (uint16_t)s0;
+    }
     int par = 0;
     double G, MU;     // column max (all states); max over the voiced states without an observation
     int kg;
@@ -950,8 +992,12 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     end_of_step(myv, observed);
     if (p.live_states != nullptr && tid == 0 && vt_begin == 0) p.live_states[f0] = kg;
 
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
+    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#endif
     int cur = 0;
     for (int t = t_lo; t < t_hi; ++t) {
+        VIT_TICK(5)
         double lp = 0.0;
         if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
         const int lpar = par ^ 1;      // parity the previous end_of_step wrote its lists under
@@ -972,6 +1018,13 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         const int reach_lo = act ? bl - H : 0x7fffffff;           // low source e in reach  <=> e >= reach_lo
         const int reach_hi = act ? bl - (B - 2 * H) : -1;         // high source e in reach <=> e <= reach_hi
 
+        double best = -INFINITY;
+        int bi = 0;
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 32)
+        if (vp) {   // timing experiment: voiced waves skip all candidate work (values are wrong)
+#else
+        {
+#endif
         // ---- unvoiced sources (v = 1): always the full band, two interleaved half chains ----------
         double best1 = -INFINITY, best1b = -INFINITY;
         int code1 = 0, code1b = 0;
@@ -1018,6 +1071,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         }
 #endif
 
+        VIT_TICK(0)
         // ---- voiced sources (v = 0) ------------------------------------------------------------------
         // Exact pruning.  Voiced states whose previous-frame observation was log(tiny) carry that -708
         // in their value.  No candidate built on one of them can exceed MU + lmax (MU = their column
@@ -1025,7 +1079,6 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         // strictly below the unvoiced chain's result in every lane of the wave, such sources can neither
         // win nor tie anywhere in the wave, and only the observed voiced states -- a handful per frame,
         // listed in ascending bin order by the previous step -- remain to be examined.
-        double best = -INFINITY;
         int src = 0;
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 8)
         const bool list_only = true;
@@ -1102,7 +1155,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             }
 #endif
         }
-        int bi = src;
+        VIT_TICK(1)
+        bi = src;
         if (best1 > best) { best = best1; bi = B + src1; }
         // the one out-of-band candidate that can win: the previous column's arg-max
         {
@@ -1113,29 +1167,32 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
                 if (cand > best || (cand == best && kg < bi)) { best = cand; bi = kg; }
             }
         }
+        }
         myv = -INFINITY;
         observed = false;
         if (act) {
             myv = lp + best;
             observed = !vp && lp != p.log_tiny;
             store_value(cur ^ 1, myv);
-            ring[((t - 1) % C) * S + j] = (uint16_t)bi;
             ptr[(int64_t)t * S + j] = (uint16_t)bi;
+            const uint16_t o = ((t - 1) % C == 0) ? (uint16_t)bi : org[oc * S + bi];
+            org[(oc ^ 1) * S + j] = o;
+            if (t % C == 0 || t == T - 1) cmap[(int64_t)((t - 1) / C) * S + j] = o;
         }
+        oc ^= 1;
+        VIT_TICK(2)
         end_of_step(myv, observed);
+        VIT_TICK(3)
         if (p.live_states != nullptr && tid == 0) p.live_states[f0 + t] = kg;
         cur ^= 1;
-        if (t % C == 0 || t == T - 1) {
-            const int cc = (t - 1) / C;
-            if (act) {
-                int s = j;
-                for (int tt = t; tt > cc * C; --tt)      // steps of an earlier launch (streaming): pointers from HBM
-                    s = tt >= t_lo ? ring[((tt - 1) % C) * S + s] : ptr[(int64_t)tt * S + s];
-                cmap[(int64_t)cc * S + j] = (uint16_t)s;
-            }
-            __syncthreads();
-        }
+        VIT_TICK(4)
     }
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
+    if (blockIdx.x == 0 && lane == 0) {
+        for (int k = 0; k < 6; ++k) atomicAdd((unsigned long long *)&g_vit_dbg[wid * 8 + k], (unsigned long long)tacc[k]);
+        atomicAdd((unsigned long long *)&g_vit_dbg[wid * 8 + 7], (unsigned long long)(t_hi - t_lo));
+    }
+#endif
 
     if (t_hi < T) {                       // more launches follow: hand the column over
         if (act) vst[j] = myv;
@@ -1155,6 +1212,16 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
     }
 }
+
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
+hipError_t viterbi_debug_fetch(long long *dst, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vit_dbg), sizeof(long long) * 128);
+    if (e == hipSuccess && reset) { static long long z[128]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_vit_dbg), z, sizeof(z)); }
+    return e;
+}
+#else
+hipError_t viterbi_debug_fetch(long long *dst, bool) { for (int i = 0; i < 128; ++i) dst[i] = 0; return hipSuccess; }
+#endif
 
 template <int H>
 static size_t viterbi_band_lds(const PassParams &p, bool lt_lds) {
