@@ -44,6 +44,8 @@ struct aegis_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
+    hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
+    hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
     int64_t max_frames_per_pass = 0;
     mutable std::string err;
@@ -219,6 +221,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRTHIP(hipSetDevice(c.device));
     CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
+    CRTHIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
     CRTHIP(cqt_configure());
 
@@ -253,6 +257,7 @@ void aegis_destroy(aegis_handle *h) {
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
@@ -264,6 +269,8 @@ void aegis_destroy(aegis_handle *h) {
         free_buf(*b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
+    if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    if (h->copy_event) (void)hipEventDestroy(h->copy_event);
     delete h;
 }
 
@@ -290,9 +297,17 @@ double aegis_last_kernel_ms(const aegis_handle *h, const char *name) {
     return it == h->last_ms.end() ? -1.0 : it->second;
 }
 
+// Host-resident input of aegis_analyze_batch: the samples each time chunk needs are copied on stream3 right
+// before that chunk's frame stage is enqueued, so the transfer hides behind the pipeline instead of preceding it.
+struct HostFeed {
+    const float *const *pcm;      // [n_clips] host pointers
+    float *dst;                   // packed device buffer (== d_pcm)
+    std::vector<int64_t> copied;  // samples of each clip already enqueued
+};
+
 static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                  int32_t n_clips, double rake_sensitivity, uint32_t stages,
-                                 aegis_outputs *dout, void *stream_v, int32_t sync);
+                                 aegis_outputs *dout, void *stream_v, int32_t sync, HostFeed *feed = nullptr);
 
 int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                int32_t n_clips, double rake_sensitivity, uint32_t stages,
@@ -304,7 +319,7 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
 
 static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                  int32_t n_clips, double rake_sensitivity, uint32_t stages,
-                                 aegis_outputs *dout, void *stream_v, int32_t sync) {
+                                 aegis_outputs *dout, void *stream_v, int32_t sync, HostFeed *feed) {
     if (!h) return AEGIS_ERR_INVALID;
     if (n_clips < 0 || (n_clips > 0 && (!sample_offsets || !dout))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
     if (n_clips == 0) return AEGIS_OK;
@@ -448,6 +463,25 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             p.n_sel = m.sel_off[(size_t)k * (nc + 1) + nc];
             p.vt_begin = chunk_lo(k);
             p.vt_end = (k == nk - 1) ? INT64_MAX : chunk_hi(k);
+            if (feed) {      // frame t reads samples [t*hop - 1024, t*hop + 1024)
+                bool any = false;
+                for (int i = 0; i < nc; ++i) {
+                    const int64_t n = sample_offsets[first + i + 1] - sample_offsets[first + i];
+                    const int64_t fr = std::min(frames[first + i], chunk_hi(k));
+                    const int64_t need = (k == nk - 1) ? n : std::min(n, (fr - 1) * (int64_t)t.hop + t.n_fft / 2);
+                    int64_t &done = feed->copied[first + i];
+                    if (need > done) {
+                        HIPCHK(h, hipMemcpyAsync(feed->dst + sample_offsets[first + i] + done, feed->pcm[first + i] + done,
+                                                 (size_t)(need - done) * 4, hipMemcpyHostToDevice, h->stream3));
+                        done = need;
+                        any = true;
+                    }
+                }
+                if (any) {
+                    HIPCHK(h, hipEventRecord(h->copy_event, h->stream3));
+                    HIPCHK(h, hipStreamWaitEvent(s, h->copy_event, 0));
+                }
+            }
             begin_event(h, "frame_fft", s); launch_frame_fft(p, h->dt, s); end_event(h, s);
             if (py) {
                 begin_event(h, "yin_seq", s); launch_yin_seq(p, h->dt, s); end_event(h, s);
@@ -503,10 +537,8 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     int rc;
     if ((rc = ensure(h, h->io_pcm, (size_t)std::max<int64_t>(off[n_clips], 1) * 4)) != AEGIS_OK) return rc;
     hipStream_t s = h->stream;
-    for (int i = 0; i < n_clips; ++i)
-        if (n_samples[i] > 0)
-            HIPCHK(h, hipMemcpyAsync(static_cast<float *>(h->io_pcm.p) + off[i], pcm[i], n_samples[i] * 4,
-                                     hipMemcpyHostToDevice, s));
+    // the previous call's kernels may still read io_pcm only if it returned without a sync -- it never does
+    HostFeed feed{pcm, static_cast<float *>(h->io_pcm.p), std::vector<int64_t>((size_t)n_clips, 0)};
     aegis_outputs d{};
     const int nm = h->tab.n_mels;
     if ((stages & AEGIS_STAGE_PYIN) && out->f0) { if ((rc = ensure(h, h->io_f0, F * 8))) return rc; d.f0 = static_cast<double *>(h->io_f0.p); }
@@ -516,7 +548,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if ((stages & AEGIS_STAGE_RAKE) && out->rake_mask) { if ((rc = ensure(h, h->io_rake, F))) return rc; d.rake_mask = static_cast<uint8_t *>(h->io_rake.p); }
     if ((stages & AEGIS_STAGE_MEL) && out->S_dB) { if ((rc = ensure(h, h->io_sdb, F * nm * 4))) return rc; d.S_dB = static_cast<float *>(h->io_sdb.p); }
     rc = analyze_device_locked(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
-                               rake_sensitivity, stages, &d, s, 0);
+                               rake_sensitivity, stages, &d, s, 0, &feed);
     if (rc != AEGIS_OK) return rc;
     if (d.f0) HIPCHK(h, hipMemcpyAsync(out->f0, d.f0, F * 8, hipMemcpyDeviceToHost, s));
     if (d.voiced_flag) HIPCHK(h, hipMemcpyAsync(out->voiced_flag, d.voiced_flag, F, hipMemcpyDeviceToHost, s));
