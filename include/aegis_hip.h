@@ -110,7 +110,8 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
  * fmin, n_bins, bins_per_octave, filter_scale, norm=1, window='hann', scale=True, pad_mode='constant')
  * approximates octave by octave (wavelet atoms of librosa 0.10 filters.wavelet), as a block-sparse float32
  * GEMM on the MFMA units.  Host PCM in, |C| out: per clip [n_bins, F_clip] C-order, clip after clip.
- * Zero arguments take the defaults n_bins=84, bins_per_octave=12, fmin=C1, filter_scale=1.  Blocking. */
+ * Zero arguments take the defaults n_bins=84, bins_per_octave=12, fmin=C1, filter_scale=1.  n_bins <= 256 (chroma_cqt's
+ * 7 x 36 = 252 bins run as three launches of 11 row tiles); the longest atom may span up to 131 072 taps.  Blocking. */
 int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
               int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out);
 

@@ -7,7 +7,7 @@
 
 namespace aegis {
 
-constexpr int kCqtMaxTiles = 16;     // 16 filter rows (8 bins x re/im) per tile -> up to 128 bins
+constexpr int kCqtMaxTiles = 32;     // 16 filter rows (8 bins x re/im) per tile -> up to 256 bins (chroma_cqt: 252)
 constexpr int kCqtChunk = 512;       // samples of every frame staged in LDS per pass
 constexpr int kCqtFrames = 64;       // frames per workgroup (4 MFMA column tiles)
 

@@ -25,7 +25,7 @@ constexpr int kPassTaps = 256;          // taps per pass (see cqt_bank_index)
 size_t cqt_bank_index(int half, int kidx, int row);
 
 const char *build_cqt_bank(CqtBank &b, int sr, int n_bins, double fmin, int bins_per_octave, double filter_scale) {
-    if (n_bins < 1 || n_bins > 8 * kCqtMaxTiles) return "cqt: n_bins must be 1..128";
+    if (n_bins < 1 || n_bins > 8 * kCqtMaxTiles) return "cqt: n_bins must be 1..256";
     if (!(fmin > 0) || bins_per_octave < 1 || !(filter_scale > 0) || sr <= 0) return "cqt: bad parameters";
     b.n_bins = n_bins; b.sr = sr; b.fmin = fmin; b.bins_per_octave = bins_per_octave; b.filter_scale = filter_scale;
     b.n_tiles = (n_bins + 7) / 8;
@@ -49,7 +49,7 @@ const char *build_cqt_bank(CqtBank &b, int sr, int n_bins, double fmin, int bins
         b.offset[T] = total;
         total += (int64_t)2 * b.half[T] * 16;
     }
-    if (b.half[0] > 64 * kCqtChunk) return "cqt: lowest bin needs more than 65536 taps";
+    if (b.half[0] > 128 * kCqtChunk) return "cqt: lowest bin needs more than 131072 taps";
     b.data.assign((size_t)total, 0.0f);
     for (int k = 0; k < n_bins; ++k) {
         const int T = k / 8, L = len[k];

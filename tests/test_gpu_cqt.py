@@ -53,3 +53,35 @@ def test_other_hops():
         check(got[0], y, hop_length=hop)
         check(got[1], y[:30000], hop_length=hop)
         h.close()
+
+
+def test_chroma_cqt_and_similarity(tmp_path):
+    """chroma_cqt (252-bin CQT on the GPU + host folding) and the auto-matcher's score against oracle/chroma.py
+    (auto_matcher.py:52-83).  The score tolerance covers float32 GEMM error and the -80 dB clamp of S_dB."""
+    from oracle import chroma as ochroma
+    from spectrogram_midi_amd import audio_io, similarity
+    h = _lib.Handle()
+    a = signals.c_major_scale(sr=44100)[:3 * 44100]
+    b = signals.polyphonic_clip(3.0, seed=7)
+    got = similarity.chroma_cqt(h, [a, b])
+    for g, y in zip(got, (a, b)):
+        ref = ochroma.chroma_cqt(y)
+        assert g.shape == ref.shape == (12, 1 + len(y) // 512) and g.dtype == np.float32
+        assert np.abs(g - ref).max() < 2e-4 and np.abs(g.max(axis=0) - 1.0).max() < 1e-6
+    # the scale's first note is C4: pitch class 0 dominates its frames
+    assert int(np.argmax(got[0][:, 20])) == 0
+    for x, y in ((a, a), (a, b), (a, 0.3 * a + 0.05 * b[:len(a)])):
+        s = similarity.similarity_arrays(h, x, y)
+        assert abs(s - ochroma.similarity(x, y)) < 2e-4, (s, ochroma.similarity(x, y))
+    assert abs(similarity.similarity_arrays(h, a, a) - 1.0) < 1e-6
+    assert similarity.similarity_arrays(h, a[:20000], a[:20000]) == 0.0          # < 0.5 s
+    # file-level mirror of _calculate_similarity: path + WAV bytes, catch-all -> 0.0
+    p = str(tmp_path / "orig.wav")
+    audio_io.write_wav(p, a, 44100)
+    q = str(tmp_path / "synth.wav")
+    audio_io.write_wav(q, b, 44100)
+    s = similarity._calculate_similarity(p, open(q, "rb").read(), 44100, handle=h)
+    a16, b16 = audio_io.read_wav(p, 44100), audio_io.read_wav(q, 44100)
+    assert abs(s - ochroma.similarity(a16, b16)) < 2e-4
+    assert similarity._calculate_similarity(str(tmp_path / "missing.wav"), b"", 44100, handle=h) == 0.0
+    h.close()

@@ -83,7 +83,46 @@ def test_wav_roundtrip(tmp_path):
     part = audio_io.read_wav(p, 44100, offset=0.1, duration=0.2)
     np.testing.assert_array_equal(part, z[4410:4410 + 8820])
     with pytest.raises(ValueError):
-        audio_io.read_wav(p, 22050)
+        audio_io.read_wav(p, 22050, resample_mismatch=False)
+
+
+def test_loader_resamples_like_librosa_polyphase(tmp_path):
+    """librosa.load semantics: native-rate offset/duration, channel mean, then resample to
+    ceil(n * ratio) samples.  The FIR is scipy's polyphase (librosa res_type="polyphase"), not soxr_hq."""
+    import wave
+    t = np.arange(22050) / 22050.0
+    left, right = 0.5 * np.sin(2 * np.pi * 440 * t), 0.25 * np.sin(2 * np.pi * 880 * t)
+    p = str(tmp_path / "stereo22k.wav")
+    pcm = np.clip(np.round(np.stack([left, right], 1) * 32768.0), -32768, 32767).astype("<i2")
+    with wave.open(p, "wb") as w:
+        w.setnchannels(2); w.setsampwidth(2); w.setframerate(22050); w.writeframes(pcm.tobytes())
+    with pytest.warns(UserWarning, match="resampling 22050 -> 44100"):
+        y = audio_io.read_wav(p, 44100)
+    assert y.dtype == np.float32 and len(y) == 44100
+    t2 = np.arange(44100) / 44100.0
+    want = 0.5 * (0.5 * np.sin(2 * np.pi * 440 * t2) + 0.25 * np.sin(2 * np.pi * 880 * t2))
+    assert np.abs(y[2000:-2000] - want[2000:-2000]).max() < 1e-3
+    with pytest.warns(UserWarning):
+        part = audio_io.read_wav(p, 44100, offset=0.25, duration=0.5)
+    assert len(part) == 22050
+    assert len(audio_io.resample(np.zeros(1001, np.float32), 44100, 22050)) == 501      # ceil(n * ratio)
+    np.testing.assert_array_equal(audio_io.read_wav_bytes(open(p, "rb").read(), 22050),
+                                  audio_io.read_wav(p, 22050))
+
+
+def test_cq_to_chroma_matches_oracle_and_structure():
+    from oracle import chroma as ochroma
+    from spectrogram_midi_amd import similarity
+    m = similarity.cq_to_chroma(252)
+    np.testing.assert_array_equal(m, ochroma.cq_to_chroma(252))
+    assert m.shape == (12, 252) and m.dtype == np.float32
+    assert (m.sum(axis=0) == 1).all() and (m.sum(axis=1) == 21).all()          # 7 octaves x 3 bins per class
+    # C1 is bin 0: bins 251, 0, 1 (one third-semitone either side) fold onto pitch class C
+    assert m[0, 0] == 1 and m[0, 1] == 1 and m[0, 35] == 1 and m[1, 2] == 1
+    a = similarity.cq_to_chroma(84, bins_per_octave=12, fmin=440.0)             # A4 first: class 9 leads
+    assert a[9, 0] == 1 and a[10, 1] == 1
+    with pytest.raises(ValueError):
+        similarity.cq_to_chroma(84, bins_per_octave=14)
 
 
 def test_out_of_scope_methods_raise():
