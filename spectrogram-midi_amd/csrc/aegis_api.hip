@@ -7,6 +7,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -44,6 +45,7 @@ struct aegis_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
+    int64_t time_chunk = 1024;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
     hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
@@ -222,6 +224,10 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    if (const char *e = std::getenv("AEGIS_TIME_CHUNK")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 64 && v % kViterbiChunk == 0) h->time_chunk = v;
+    }
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
     CRTHIP(cqt_configure());
@@ -426,15 +432,17 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // frame-stage kernels are wide.  Long clips are therefore cut into time chunks of kTimeChunk
         // Viterbi steps: chunk k's frame stage runs on `s` while chunk k-1's Viterbi runs on the
         // handle's second stream, carrying its column of values exactly (vstate) across launches.
-        constexpr int64_t kTimeChunk = 2048;      // multiple of kViterbiChunk
+        // The frame stage (4.8 us per column of 64 clips) and the Viterbi (5.0 us per step) run at nearly the same
+        // rate, so every growth of the chunk size stalls the Viterbi stream by the extra frame-stage time: chunks
+        // are short and uniform (rocprofv3 timeline: 2048-step chunks behind a 256/768 ramp idled it for 6 ms).
+        const int64_t kTimeChunk = h->time_chunk;      // multiple of kViterbiChunk
         int64_t maxF = 0;
         for (int i = 0; i < nc; ++i) maxF = std::max(maxF, frames[first + i]);
         // chunk boundaries: frame 0, then 1 + (multiple of kViterbiChunk) so that every launch starts
-        // on a back-pointer-map boundary.  The first chunks are short (256, 768 steps) so the
-        // Viterbi stream starts early; nothing overlaps the first chunk's frame stage.
+        // on a back-pointer-map boundary; nothing overlaps the first (half-size) chunk's frame stage.
         std::vector<int64_t> cb{0};
         if (py && maxF > kTimeChunk + kTimeChunk / 2) {
-            for (int64_t e : {(int64_t)256, (int64_t)1024}) cb.push_back(1 + e);
+            cb.push_back(1 + kTimeChunk / 2);
             while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) cb.push_back(cb.back() + kTimeChunk);
         }
         cb.push_back(maxF);
