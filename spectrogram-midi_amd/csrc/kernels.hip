@@ -57,19 +57,38 @@ __device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_doub
 // result in `a`, `b` is the second buffer.  Callers synchronise before the call; every pass
 // ends with a workgroup barrier, so all threads of the workgroup must make the same calls.
 // ------------------------------------------------------------------------------------------
+// The twiddles a thread needs do not depend on the data: in the radix-4 pass of stride NS thread j uses
+// tw[m], tw[2m], tw[3m] with m = (j & (NS-1)) * 512/NS, and j & (NS-1) only depends on j mod 256 for NS <= 256,
+// so the two butterflies of a 256-thread FFT and the one of the 512-thread FFT share them; the last radix-2
+// pass multiplies element j + 1024 by tw[j], j = lt + 256*q.  They are read from the table ONCE per workgroup
+// into registers (16 double2) instead of 3 global loads per butterfly and pass.
+struct FftTw {
+    double2 r4[4][3];   // passes NS = 4, 16, 64, 256
+    double2 last[4];    // tw[lt + 256*q]
+};
+__device__ __forceinline__ void load_fft_twiddles(FftTw &w, const double2 *__restrict__ tw, int lt) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+        const int NS = 4 << (2 * ps);
+        const int m = (lt & (NS - 1)) * (2048 / (NS * 4));
+        w.r4[ps][0] = tw[m]; w.r4[ps][1] = tw[2 * m]; w.r4[ps][2] = tw[3 * m];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) w.last[q] = tw[lt + 256 * q];
+}
+
 template <int NS, int NT>
 __device__ __forceinline__ void fft_pass_r4(const double2 *__restrict__ in, double2 *__restrict__ out,
-                                            const double2 *__restrict__ tw, int tid) {
+                                            const double2 (&w3)[3], int tid) {
 #pragma unroll
     for (int jj = 0; jj < 512 / NT; ++jj) {
         const int j = tid + jj * NT;
         const int k = j & (NS - 1);
         double2 v0 = in[j], v1 = in[j + 512], v2 = in[j + 1024], v3 = in[j + 1536];
         if (NS > 1) {
-            const int m = k * (2048 / (NS * 4));
-            v1 = cmul(v1, tw[m]);
-            v2 = cmul(v2, tw[2 * m]);
-            v3 = cmul(v3, tw[3 * m]);
+            v1 = cmul(v1, w3[0]);
+            v2 = cmul(v2, w3[1]);
+            v3 = cmul(v3, w3[2]);
         }
         const double2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3);
         double2 a3 = csub(v1, v3);
@@ -82,27 +101,29 @@ __device__ __forceinline__ void fft_pass_r4(const double2 *__restrict__ in, doub
     }
 }
 
+// hh = tid / 256 (0 for the 256-thread transforms)
 template <int NT>
 __device__ __forceinline__ void fft_pass_r2_last(const double2 *__restrict__ in, double2 *__restrict__ out,
-                                                 const double2 *__restrict__ tw, int tid) {
+                                                 const FftTw &w, int tid, int hh) {
 #pragma unroll
     for (int jj = 0; jj < 1024 / NT; ++jj) {
         const int j = tid + jj * NT;   // 0..1023, Ns = 1024 -> k = j, j0 = j
+        const double2 t = NT == 256 ? w.last[jj] : (hh ? w.last[1 + 2 * jj] : w.last[2 * jj]);
         const double2 v0 = in[j];
-        const double2 v1 = cmul(in[j + 1024], tw[j]);
+        const double2 v1 = cmul(in[j + 1024], t);
         out[j] = cadd(v0, v1);
         out[j + 1024] = csub(v0, v1);
     }
 }
 
 template <int NT>
-__device__ __forceinline__ void fft2048(double2 *a, double2 *b, const double2 *__restrict__ tw, int tid) {
-    fft_pass_r4<1, NT>(a, b, tw, tid);   __syncthreads();
-    fft_pass_r4<4, NT>(b, a, tw, tid);   __syncthreads();
-    fft_pass_r4<16, NT>(a, b, tw, tid);  __syncthreads();
-    fft_pass_r4<64, NT>(b, a, tw, tid);  __syncthreads();
-    fft_pass_r4<256, NT>(a, b, tw, tid); __syncthreads();
-    fft_pass_r2_last<NT>(b, a, tw, tid); __syncthreads();
+__device__ __forceinline__ void fft2048(double2 *a, double2 *b, const FftTw &w, int tid, int hh) {
+    fft_pass_r4<1, NT>(a, b, w.r4[0], tid);   __syncthreads();
+    fft_pass_r4<4, NT>(b, a, w.r4[0], tid);   __syncthreads();
+    fft_pass_r4<16, NT>(a, b, w.r4[1], tid);  __syncthreads();
+    fft_pass_r4<64, NT>(b, a, w.r4[2], tid);  __syncthreads();
+    fft_pass_r4<256, NT>(a, b, w.r4[3], tid); __syncthreads();
+    fft_pass_r2_last<NT>(b, a, w, tid, hh);   __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -118,6 +139,7 @@ __device__ __forceinline__ void fft2048(double2 *a, double2 *b, const double2 *_
 //   * |XW|^2 rounded through complex64 like librosa.stft -> Slaney mel -> clip max
 // 1.5 FFTs per frame instead of 3.
 // ------------------------------------------------------------------------------------------
+constexpr int kFramePairs = 4;   // frame pairs per workgroup of frame_fft_kernel
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
 __device__ long long g_frm_dbg[16];
 #define FRM_TICK(k) { const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
@@ -140,24 +162,46 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     double2 *bufA = bufs + hh * 4096, *bufB = bufA + 2048;
     float *xs = xs_all + hh * 2048, *pw = pw_all + hh * 1032, *red = red_all + hh * 128, *blk = blk_all + hh * 16;
 
-    const int64_t fs = (int64_t)blockIdx.x * 2 + hh;
-    const bool live = fs < geo_n_sel(p);
-    int c = 0;
-    int64_t base = 0, n = 0, start = 0, f = 0;
-    if (live) {
-        int64_t t;
-        map_frame(p, fs, c, t, f);
-        base = p.sample_off[c];
-        n = p.sample_off[c + 1] - base;
-        start = t * p.hop - 1024;
-    }
+    // One workgroup owns kFramePairs consecutive frame pairs (it has the CU to itself: 153 KB of LDS).  The
+    // samples of the next pair are fetched into registers while the current pair is transformed, and the FFT
+    // twiddles are read once; both used to be exposed global-memory latency in every pair.
+    struct Geo { bool live; int c; int64_t base, n, start, f; };
+    auto locate = [&](int it) {
+        Geo g{false, 0, 0, 0, 0, 0};
+        const int64_t fs = ((int64_t)blockIdx.x * kFramePairs + it) * 2 + hh;
+        g.live = it < kFramePairs && fs < geo_n_sel(p);
+        if (g.live) {
+            int64_t t;
+            map_frame(p, fs, g.c, t, g.f);
+            g.base = p.sample_off[g.c];
+            g.n = p.sample_off[g.c + 1] - g.base;
+            g.start = t * p.hop - 1024;
+        }
+        return g;
+    };
+    auto fetch = [&](const Geo &g, float (&v)[8]) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int i = lt + r * 256;
-        const int64_t idx = start + i;
-        xs[i] = (live && idx >= 0 && idx < n) ? p.pcm[base + idx] : 0.0f;
-    }
+        for (int r = 0; r < 8; ++r) {
+            const int64_t idx = g.start + lt + r * 256;
+            v[r] = (g.live && idx >= 0 && idx < g.n) ? p.pcm[g.base + idx] : 0.0f;
+        }
+    };
+    Geo geo = locate(0);
+    float nx[8];
+    fetch(geo, nx);
+    FftTw twr;
+    load_fft_twiddles(twr, tb.twiddle, lt);
+
+    for (int it = 0; it < kFramePairs; ++it) {
+    const bool live = geo.live;
+    const int c = geo.c;
+    const int64_t f = geo.f;
+    if (it > 0) __syncthreads();          // the previous pair's inverse transform still reads the buffers
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xs[lt + r * 256] = nx[r];
     if (lt == 0) smax_all[hh] = 0u;
+    geo = locate(it + 1);
+    fetch(geo, nx);                       // in flight under everything below
     __syncthreads();
     FRM_TICK(0)
 
@@ -187,7 +231,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
             p.out_rms[f] = sqrtf(total / 2048.0f);
         }
     }
-    if (!(p.stages & 0x7u)) return;
+    if (!(p.stages & 0x7u)) continue;
     FRM_TICK(1)
 
     // ---- packed forward FFT of (frame, reversed first half) ---------------------------------
@@ -197,7 +241,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
         bufA[i] = make_double2((double)xs[i], i < 1024 ? (double)xs[1024 - i] : 0.0);
     }
     __syncthreads();
-    fft2048<256>(bufA, bufB, tb.twiddle, lt);
+    fft2048<256>(bufA, bufB, twr, lt, 0);
     FRM_TICK(2)
 
     // A[k] -> bufB[k] (k <= 1024); P[k] = A[k]*B[k] kept in registers
@@ -259,7 +303,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
             if (k > 0 && k < 1024) q[2048 - k] = make_double2(u.x + v.y, u.y - v.x);   // P0 - i P1
         }
         __syncthreads();
-        fft2048<512>(q, q2, tb.twiddle, tid);
+        fft2048<512>(q, q2, twr, tid, hh);
         FRM_TICK(5)
         // FFT(conj Q) = N * conj(acf0 + i acf1)
         if (live) {
@@ -274,8 +318,9 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     }
     if ((p.stages & 0x3u) && lt == 0 && live) atomicMax(&p.clipmax[c], smax_all[hh]);
     FRM_TICK(6)
+    }   // frame pairs
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-    if (blockIdx.x == 5000 && tid == 0) { for (int k = 0; k < 7; ++k) g_frm_dbg[k] = facc[k]; }
+    if (blockIdx.x == 1000 && tid == 0) { for (int k = 0; k < 7; ++k) g_frm_dbg[k] = facc[k]; }
 #endif
 }
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
@@ -1442,7 +1487,8 @@ hipError_t viterbi_configure() {
 
 void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0 || !(p.stages & 0xFu)) return;
-    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((p.n_sel + 1) / 2)), dim3(512), kFrameLds, s, p, t);
+    const int64_t pairs = (p.n_sel + 1) / 2;
+    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((pairs + kFramePairs - 1) / kFramePairs)), dim3(512), kFrameLds, s, p, t);
 }
 void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
     if (p.n_sel == 0) return;

@@ -1,4 +1,4 @@
-"""Section cycle counters of frame_fft_kernel (workgroup 5000, thread 0), needs a -DAEGIS_ABLATE=128 build:
+"""Section cycle counters of frame_fft_kernel (workgroup 1000, thread 0, summed over its 4 frame pairs), needs a -DAEGIS_ABLATE=128 build:
 AEGIS_HIP_LIB=_ablate/lib_ab128.so python tools/frame_cycles.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
