@@ -139,14 +139,14 @@ __device__ __forceinline__ void fft2048(double2 *a, double2 *b, const FftTw &w, 
 //   * |XW|^2 rounded through complex64 like librosa.stft -> Slaney mel -> clip max
 // 1.5 FFTs per frame instead of 3.
 // ------------------------------------------------------------------------------------------
-constexpr int kFramePairs = 4;   // frame pairs per workgroup of frame_fft_kernel
+constexpr int kFramePairs = 4;   // frame pairs per workgroup of frame_fft_kernel (1 for small launches: streaming pushes)
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
 __device__ long long g_frm_dbg[16];
 #define FRM_TICK(k) { const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
 #else
 #define FRM_TICK(k)
 #endif
-__global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables tb) {
+__global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables tb, int pairs_per_wg) {
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
     long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = clock64();
 #endif
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     struct Geo { bool live; int c; int64_t base, n, start, f; };
     auto locate = [&](int it) {
         Geo g{false, 0, 0, 0, 0, 0};
-        const int64_t fs = ((int64_t)blockIdx.x * kFramePairs + it) * 2 + hh;
-        g.live = it < kFramePairs && fs < geo_n_sel(p);
+        const int64_t fs = ((int64_t)blockIdx.x * pairs_per_wg + it) * 2 + hh;
+        g.live = it < pairs_per_wg && fs < geo_n_sel(p);
         if (g.live) {
             int64_t t;
             map_frame(p, fs, g.c, t, g.f);
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables 
     FftTw twr;
     load_fft_twiddles(twr, tb.twiddle, lt);
 
-    for (int it = 0; it < kFramePairs; ++it) {
+    for (int it = 0; it < pairs_per_wg; ++it) {
     const bool live = geo.live;
     const int c = geo.c;
     const int64_t f = geo.f;
@@ -1488,7 +1488,8 @@ hipError_t viterbi_configure() {
 void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0 || !(p.stages & 0xFu)) return;
     const int64_t pairs = (p.n_sel + 1) / 2;
-    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((pairs + kFramePairs - 1) / kFramePairs)), dim3(512), kFrameLds, s, p, t);
+    const int g = pairs >= 2048 ? kFramePairs : 1;       // below ~8 workgroups per CU latency matters more than amortisation
+    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((pairs + g - 1) / g)), dim3(512), kFrameLds, s, p, t, g);
 }
 void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
     if (p.n_sel == 0) return;
