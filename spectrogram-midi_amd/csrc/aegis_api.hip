@@ -45,7 +45,7 @@ struct aegis_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
-    int64_t time_chunk = 1024;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
+    int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
     hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
@@ -442,8 +442,14 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // on a back-pointer-map boundary; nothing overlaps the first (half-size) chunk's frame stage.
         std::vector<int64_t> cb{0};
         if (py && maxF > kTimeChunk + kTimeChunk / 2) {
-            cb.push_back(1 + kTimeChunk / 2);
-            while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) cb.push_back(cb.back() + kTimeChunk);
+            // ramp: the frame stage is ~1.3x faster than the Viterbi per column, so chunks may grow by 1.25x
+            // without ever making the Viterbi stream wait; only the first (quarter-size) chunk is exposed.
+            int64_t step = std::max<int64_t>(kViterbiChunk, kTimeChunk / 4 / kViterbiChunk * kViterbiChunk);
+            cb.push_back(1 + step);
+            while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
+                step = std::min<int64_t>(kTimeChunk, (step * 5 / 4 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                cb.push_back(cb.back() + step);
+            }
         }
         cb.push_back(maxF);
         const int nk = (int)cb.size() - 1;
