@@ -189,3 +189,30 @@ def test_unaligned_clips_and_fewer_mel_bands():
     assert r["S_dB"].shape == ref.shape == (64, 118)
     np.testing.assert_allclose(r["S_dB"], ref, atol=2e-3)
     h64.close()
+
+
+def test_time_chunk_pipeline_ragged(monkeypatch):
+    """The two-stream time-chunk pipeline (frame stage of chunk k+1 under the Viterbi of chunk k, Viterbi column and
+    pointer maps carried across launches, host samples copied chunk by chunk) must not change a single bit, whatever
+    the chunk size and however ragged the batch: clips that end in different chunks, an empty clip, a clip shorter
+    than the first chunk.  AEGIS_TIME_CHUNK=64 cuts the 12 s clip into ~17 launches; the default handle runs the
+    same clips in one launch each."""
+    clips = [signals.guitar_clip(12.0, seed=5), signals.guitar_clip(0.4, seed=6), np.zeros(0, np.float32),
+             signals.polyphonic_clip(7.7, seed=7), signals.guitar_clip(3.0, seed=8)[:100003]]
+    ref_h = _lib.Handle()
+    ref = ref_h.analyze_batch(clips)
+    for chunk in ("64", "256"):
+        monkeypatch.setenv("AEGIS_TIME_CHUNK", chunk)
+        h = _lib.Handle()
+        got = h.analyze_batch(clips)
+        again = h.analyze_batch(list(reversed(clips)))[::-1]
+        for i in range(len(clips)):
+            for k in ref[i]:
+                np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"chunk {chunk} clip {i} {k}")
+                np.testing.assert_array_equal(again[i][k], ref[i][k], err_msg=f"chunk {chunk} reversed clip {i} {k}")
+        h.close()
+    monkeypatch.delenv("AEGIS_TIME_CHUNK")
+    o = oengine.audio_to_midi(clips[3])
+    np.testing.assert_array_equal(ref[3]["voiced_flag"], o["voiced_flag"])
+    np.testing.assert_allclose(np.nan_to_num(ref[3]["f0"]), o["f0"], rtol=1e-13)
+    ref_h.close()
