@@ -3,14 +3,18 @@
 //   C[2k+c, t] = sum_j G[2k+c, j] * y[t*hop + j],   G = (re, im) rows of sqrt(N_k) * atom_k(-j)
 //
 // Rows are grouped in tiles of 16 (8 bins x re/im), bins ascending = supports descending; tile T only
-// spans |j| < half[T].  One workgroup = 64 consecutive frames (4 column tiles of 16) x all row tiles.
-// The signal is staged through LDS in passes of 256 samples per frame, double buffered ([2][64][256+2]
-// floats: the +2 makes the 16 columns x 4 k-lanes of an MFMA B fragment hit 64 distinct banks); the next
-// pass is fetched to registers while the current one feeds the MFMAs.  Every wave keeps
-// accumulators for ALL row tiles (<= 11 tiles x 4 column tiles x 4 VGPRs) and takes every 4th k-step of
-// a pass, so a B fragment is read from LDS once and reused for every active row tile from registers, the
-// four waves are perfectly balanced however short the outer tiles are, and the split-K partial sums are
-// reduced once at the end through LDS.  v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulate.
+// spans |j| < half[T].  Two kernels share one filter bank (layout: cqt_bank_index):
+//   * cqt_slide_kernel (the one that runs for hop <= 512, hop % 16 == 0): 48 frames per workgroup as hop-shifted
+//     views of ONE stretch of signal held as a ring in LDS; see the comment above it;
+//   * cqt_kernel (any other hop): 64 frames (4 column tiles) per workgroup, the signal staged per frame through
+//     LDS in passes of 256 samples, double buffered ([2][64][256+1] floats: the +1 makes the 16 columns x 4
+//     k-lanes, 16 taps apart, of an MFMA B fragment hit 64 distinct banks); the next pass is fetched to
+//     registers while the current one feeds the MFMAs.
+// In both, every wave keeps accumulators for ALL row tiles of the launch (<= 11 tiles x 3 or 4 column tiles x
+// 4 registers) and owns a quarter of the taps of every pass, so a B fragment is read from LDS once and reused
+// for every active row tile from registers, the four waves are balanced however short the outer tiles are, and
+// the split-K partial sums are reduced once at the end through LDS.
+// v_mfma_f32_16x16x4_f32: exact float32 products, float32 accumulate.
 #include "cqt.h"
 #include <type_traits>
 
