@@ -895,6 +895,7 @@ template <int H>
 struct BandLT {
     double v[4][2 * H + 1];   // [v*2+v'][dd]
     double lmax[4];           // [v*2+v'] largest log-transition of that block over ALL row classes
+    double lmax_all;          // largest log-transition of the whole matrix
 };
 
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
@@ -915,8 +916,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     double *valI = reinterpret_cast<double *>(smem_raw);   // [2 buf][2 v][PADB], index b + H
     double *valE = valI + 4 * PADB;                        // [2 buf][2 v][2H]
     double *rv = valE + 8 * H;                             // [2][16]  wave maxima
-    double *rvU = rv + 32;                                 // [2][16]  wave maxima over unobserved voiced states
-    unsigned long long *omask = reinterpret_cast<unsigned long long *>(rvU + 32);   // [2][16] observed-state ballots of the voiced waves
+    unsigned long long *omask = reinterpret_cast<unsigned long long *>(rv + 64);   // [2][16] observed-state ballots of the voiced waves (32 doubles after rv are spare)
     int *ri = reinterpret_cast<int *>(omask + 32);         // [2][16]
     uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [C][S]
     double *ltl = reinterpret_cast<double *>(
@@ -924,7 +924,6 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
     const int vp = __builtin_amdgcn_readfirstlane(tid >= BP ? 1 : 0);
-    const int nvw = BP >> 6;                      // voiced waves are [0, nvw)
     const int b2 = tid - vp * BP;
     const bool act = b2 < B;
     const int b2c = act ? b2 : 0;
@@ -996,14 +995,15 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         org[j] = (uint16_t)s0;
     }
     int par = 0;
-    double G, MU;     // column max (all states); max over the voiced states without an observation
+    double G;                 // column max (all states)
+    double Gp = INFINITY;     // the column max one step earlier (unknown at the first step of a launch)
     int kg;
     // End-of-step bookkeeping, one barrier: block arg-max (lowest index on ties; DPP wave max -> first
-    // lane holding it -> one LDS slot per wave -> every wave reduces the <= 16 slots), the max over
-    // the unobserved voiced states, and one ballot mask per voiced wave marking the observed voiced states.
+    // lane holding it -> one LDS slot per wave -> every wave reduces the <= 16 slots) and one ballot mask
+    // per voiced wave marking the observed voiced states.
     auto end_of_step = [&](double v, bool obs) {
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 2)
-        __syncthreads(); G = v; kg = 0; MU = INFINITY; return;
+        __syncthreads(); G = v; kg = 0; return;
 #endif
         double m = row16_prefix_max(v);
         m = dpp_fmax<0x142, 0xa>(m);   // row_bcast:15
@@ -1011,11 +1011,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         const double wm = read_lane_f64(m, 63);
         const unsigned long long eq = __ballot(v == wm);
         if (!vp) {                     // wave-uniform
-            double u = row16_prefix_max((act && !obs) ? v : -INFINITY);
-            u = dpp_fmax<0x142, 0xa>(u);
-            u = dpp_fmax<0x143, 0xc>(u);
             const unsigned long long om = __ballot(obs);
-            if (lane == 63) rvU[par * 16 + wid] = u;
             if (lane == 0) omask[par * 16 + wid] = om;
         }
         if (lane == 0) {
@@ -1023,13 +1019,12 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             ri[par * 16 + wid] = eq ? vp * B + wlo + (int)__ffsll((long long)eq) - 1 : 0x7fffffff;
         }
         __syncthreads();
-        double a = -INFINITY, au = -INFINITY;
+        double a = -INFINITY;
         int ai = 0x7fffffff;
         if (lane < nw) { a = rv[par * 16 + lane]; ai = ri[par * 16 + lane]; }
-        if (lane < nvw) au = rvU[par * 16 + lane];
         const double pm = row16_prefix_max(a);
+        Gp = G;
         G = read_lane_f64(pm, 15);
-        MU = read_lane_f64(row16_prefix_max(au), 15);
         const unsigned long long eq2 = __ballot(a == G) & 0xffffull;
         kg = __builtin_amdgcn_readlane(ai, eq2 ? (int)__ffsll((long long)eq2) - 1 : 0);
         par ^= 1;
@@ -1119,8 +1114,10 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         VIT_TICK(0)
         // ---- voiced sources (v = 0) ------------------------------------------------------------------
         // Exact pruning.  Voiced states whose previous-frame observation was log(tiny) carry that -708
-        // in their value.  No candidate built on one of them can exceed MU + lmax (MU = their column
-        // max, lmax = largest log-transition of the block; rounding is monotone).  If that bound is
+        // in their value: value = log(tiny) + (best candidate out of the column before), and no candidate out of
+        // that column exceeds Gp + lmax_all (Gp = its maximum; rounding is monotone), so MUb = log(tiny) +
+        // (Gp + lmax_all) bounds every such state without a reduction over them.  No candidate built on one of
+        // them can then exceed MUb + lmax (lmax = largest log-transition of the block).  If that bound is
         // strictly below the unvoiced chain's result in every lane of the wave, such sources can neither
         // win nor tie anywhere in the wave, and only the observed voiced states -- a handful per frame,
         // listed in ascending bin order by the previous step -- remain to be examined.
@@ -1130,7 +1127,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #elif defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 16)
         const bool list_only = false;
 #else
-        const bool list_only = LT_LDS && __all(!act || (MU + blt.lmax[0 * 2 + vp] < best1));
+        const double MUb = p.log_tiny + (Gp + blt.lmax_all);
+        const bool list_only = LT_LDS && __all(!act || (MUb + blt.lmax[0 * 2 + vp] < best1));
 #endif
         if (list_only) {
             // observed bins within reach of this wave's targets: [wlo - H, whi + H] spans <= 3 mask words
@@ -1518,6 +1516,7 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
                 blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width,
                                                 host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
             }
+            blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
             hipLaunchKernelGGL((viterbi_band_kernel<25, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
                                viterbi_band_lds<25>(p, true), s, p, t, blt);
             return hipGetLastError();
@@ -1529,6 +1528,7 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
                 blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width,
                                                 host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
             }
+            blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
             hipLaunchKernelGGL((viterbi_band_kernel<50, false>), dim3((unsigned)p.n_clips), dim3(2 * BP),
                                viterbi_band_lds<50>(p, false), s, p, t, blt);
             return hipGetLastError();
