@@ -191,7 +191,10 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name);
 /* Copies an intermediate of the most recent pass (device -> host), for stage-level
  * parity tests.  name in {"acf" f64[F*lag_stride], "yin" f64[F*yin_stride],
  * "logobs" f64[F*obs_stride], "logunv" f64[F], "states" i32[F], "melpow" f32[F*n_mels]}.
- * Returns the element count available; copies min(count, cap). */
+ * Returns the element count available; copies min(count, cap).
+ * Profiling builds only (csrc/Makefile EXTRA=-DAEGIS_ABLATE=64|128, -DCQT_ABLATE=8; zeros otherwise):
+ * "viterbi_cycles" i64[16 waves][8], "frame_cycles" i64[16], "cqt_cycles" i64[16] -- in-kernel s_memtime
+ * section counters read by tools/viterbi_cycles.py, frame_cycles.py, cqt_cycles.py (reading resets them). */
 int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t cap);
 
 /* Kernel timing of the most recent aegis_analyze_batch_device() with sync != 0,
