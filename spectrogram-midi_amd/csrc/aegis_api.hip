@@ -245,6 +245,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRT(upload_table(h, t.boltz_fact, &h->dt.boltz_fact));
     CRT(upload_table(h, t.boltz_exp, &h->dt.boltz_exp));
     CRT(upload_table(h, t.log_trans_band, &h->dt.lt_band));
+    if (!t.log_trans_pack.empty()) CRT(upload_table(h, t.log_trans_pack, &h->dt.lt_pack));
     CRT(upload_table(h, t.freqs, &h->dt.freqs));
     {
         const double *tw = nullptr;

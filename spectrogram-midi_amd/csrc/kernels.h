@@ -20,6 +20,7 @@ struct DevTables {
     const double *boltz_fact;  // [n]
     const double *boltz_exp;   // [n]
     const double *lt_band;     // [4][n_cls][width]
+    const double *lt_pack;     // [2 (stay, switch)][3H^2+3H+2] packed band table (kernels.hip pk_*), or nullptr
     const double *freqs;       // [n_bins]
     const double2 *twiddle;    // [2048]
 };

@@ -891,6 +891,17 @@ __device__ __forceinline__ double read_lane_f64(double v, int l) {
 // Interior-row log-transition table, passed BY VALUE: kernel arguments live in the kernarg
 // segment, which the compiler reads with scalar loads (s_load_dwordx16) -- the 2(2H+1) table
 // operands of a step then sit in SGPRs and cost no vector memory traffic or VGPRs.
+// Packed band table kept in LDS: the four (v,v') blocks of log(kron(loop, local) + tiny) are only two distinct ones
+// (loop is symmetric: "stay" = v == v', "switch"), and an edge row only reaches the targets that exist, so a block
+// is [sentinel][low-edge rows e = 0..H-1: dd = H-e..2H][interior row: dd = 0..2H][high-edge rows e = 0..H-1:
+// dd = 0..2H-1-e] = 3H^2 + 3H + 2 entries (15.6 KB at H = 25, 61 KB at H = 50 -- the full [4][2H+1][2H+1] table of
+// the 22.05 kHz band would be 326 KB).
+template <int H> __host__ __device__ constexpr int pk_lo_start(int e) { return 1 + e * (H + 1) + e * (e - 1) / 2; }
+template <int H> __host__ __device__ constexpr int pk_int_start() { return 1 + H * (H + 1) + H * (H - 1) / 2; }
+template <int H> __host__ __device__ constexpr int pk_hi_start(int e) { return pk_int_start<H>() + (2 * H + 1) + 2 * H * e - e * (e - 1) / 2; }
+template <int H> __host__ __device__ constexpr int pk_size() { return 3 * H * H + 3 * H + 2; }
+__host__ __device__ constexpr bool band_table_packed(int H) { return H > 25; }
+
 template <int H>
 struct BandLT {
     double v[4][2 * H + 1];   // [v*2+v'][dd]
@@ -918,9 +929,13 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     double *rv = valE + 8 * H;                             // [2][16]  wave maxima
     unsigned long long *omask = reinterpret_cast<unsigned long long *>(rv + 64);   // [2][16] observed-state ballots of the voiced waves (32 doubles after rv are spare)
     int *ri = reinterpret_cast<int *>(omask + 32);         // [2][16]
-    uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [C][S]
+    uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [2][S] chunk-origin maps
     double *ltl = reinterpret_cast<double *>(
-        smem_raw + (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)C * S * 2 + 15) / 16) * 16);
+        smem_raw + (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)2 * S * 2 + 15) / 16) * 16);   // [2][NP]
+    constexpr int NP = pk_size<H>();
+    // The packed layout costs a few scalar multiplies per list entry (row starts are quadratic in the class); the
+    // 44.1 kHz band (H = 25) keeps the full table, whose 83 KB fit; the 22.05 kHz band (H = 50) needs the packing.
+    constexpr bool PK = LT_LDS && band_table_packed(H);
 
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
     const int vp = __builtin_amdgcn_readfirstlane(tid >= BP ? 1 : 0);
@@ -938,12 +953,20 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     // LDS copy of the band table (edge rows + list lookups).  Slot [class 0][dd = 0] of every (v,v')
     // block is never a real transition (it would be a target bin of -H): it holds the -inf sentinel
     // that out-of-reach (lane, source) pairs are redirected to.
-    const double *lt_e0;   // block (v = 0, v' = vp); the v = 1 block sits 2*NC*W further
-    if (LT_LDS) {
+    // Slot 0 of each packed block holds the -inf sentinel that out-of-reach (lane, source) pairs are redirected to.
+    const double *lt_e0, *lt_e1;   // blocks (v = 0 -> v' = vp) and (v = 1 -> v' = vp)
+    if (PK) {
+        for (int i = tid; i < 2 * NP; i += nthr) ltl[i] = (i % NP == 0) ? -INFINITY : tb.lt_pack[i];
+        lt_e0 = ltl + (vp ? NP : 0);            // "stay" block first, "switch" block second
+        lt_e1 = ltl + (vp ? 0 : NP);
+    } else if (LT_LDS) {
+        // full table; slot [class 0][dd = 0] of every block is never a real transition (target bin -H): sentinel
         for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = (i % (NC * W) == 0) ? -INFINITY : tb.lt_band[i];
         lt_e0 = ltl + (size_t)vp * NC * W;
+        lt_e1 = lt_e0 + (size_t)2 * NC * W;
     } else {
         lt_e0 = tb.lt_band + (size_t)vp * NC * W;
+        lt_e1 = lt_e0 + (size_t)2 * NC * W;
     }
     const double *lti0 = blt.v[0 * 2 + vp];   // interior row, source v = 0, target v' = vp
     const double *lti1 = blt.v[1 * 2 + vp];   // source v = 1
@@ -1046,15 +1069,15 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         const double *vi1 = valI + (cur * 2 + 1) * PADB + b2c;
         const double *ve0 = valE + (cur * 2 + 0) * 2 * H;
         const double *ve1 = valE + (cur * 2 + 1) * 2 * H;
-        const double *lt_e1 = lt_e0 + (size_t)2 * NC * W;
         // edge sources: table offset of (source e, this lane) = lane base + e*(W-1); pairs out of
         // reach are redirected to the -inf sentinel (LDS copy) or predicated (global table).
         // The opaque copy of b' keeps these cheap per-step integer ops from being hoisted out of
         // the time loop into ~50 live registers.
         int bl = b2c;
         asm volatile("" : "+v"(bl));
-        const int ebase_lo = bl + H;                              // source b = e,      class e
-        const int ebase_hi = (bl - B + 2 * H) + (H + 1) * W;      // source b = B-H+e,  class H+1+e
+        // full table: [class][dd], class e resp. H+1+e, dd = b' - b + H; packed: row start + (dd - first dd of the row)
+        auto eoff_lo = [&](int e) { return PK ? pk_lo_start<H>(e) + bl : (bl + H) + e * (W - 1); };
+        auto eoff_hi = [&](int e) { return PK ? pk_hi_start<H>(e) + (bl - B + 2 * H - e) : (bl - B + 2 * H) + (H + 1) * W + e * (W - 1); };
         const int reach_lo = act ? bl - H : 0x7fffffff;           // low source e in reach  <=> e >= reach_lo
         const int reach_hi = act ? bl - (B - 2 * H) : -1;         // high source e in reach <=> e <= reach_hi
 
@@ -1089,7 +1112,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #pragma unroll
             for (int e = 0; e < H; ++e) {
                 const bool ok = e >= reach_lo;
-                const int off = (LT_LDS && !ok) ? kSentinel : ebase_lo + e * (W - 1);
+                const int off = (LT_LDS && !ok) ? kSentinel : eoff_lo(e);
                 const double cand1 = (LT_LDS || ok) ? ve1[e] + lt_e1[off] : -INFINITY;
                 if (cand1 > eb1) ec1 = e;
                 eb1 = fmax(eb1, cand1);
@@ -1102,7 +1125,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #pragma unroll
             for (int e = 0; e < H; ++e) {
                 const bool ok = e <= reach_hi;
-                const int off = (LT_LDS && !ok) ? kSentinel : ebase_hi + e * (W - 1);
+                const int off = (LT_LDS && !ok) ? kSentinel : eoff_hi(e);
                 const double cand1 = (LT_LDS || ok) ? ve1[H + e] + lt_e1[off] : -INFINITY;
                 if (cand1 > eb1) ec1 = e;
                 eb1 = fmax(eb1, cand1);
@@ -1144,9 +1167,11 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
                     m &= m - 1;
                     const bool lo_e = bo < H, hi_e = bo > B - 1 - H;
                     const double vo = (lo_e || hi_e) ? ve0[lo_e ? bo : bo - B + 2 * H] : valI[(cur * 2 + 0) * PADB + bo + H];
-                    const int cl = lo_e ? bo : (hi_e ? bo - (B - 1 - 2 * H) : H);
+                    const int rowbase = !PK ? (lo_e ? bo : (hi_e ? bo - (B - 1 - 2 * H) : H)) * W
+                                            : lo_e ? pk_lo_start<H>(bo) - (H - bo)
+                                                   : (hi_e ? pk_hi_start<H>(bo - (B - H)) : pk_int_start<H>());   // scalar
                     const int dd = b2c - bo + H;
-                    const int off = (act && (unsigned)dd < (unsigned)W) ? cl * W + dd : kSentinel;
+                    const int off = (act && (unsigned)dd < (unsigned)W) ? rowbase + dd : kSentinel;
                     const double cand = vo + lt_e0[off];
                     if (cand > best) src = bo;
                     best = fmax(best, cand);
@@ -1176,7 +1201,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #pragma unroll
                 for (int e = 0; e < H; ++e) {
                     const bool ok = e >= reach_lo;
-                    const int off = (LT_LDS && !ok) ? kSentinel : ebase_lo + e * (W - 1);
+                    const int off = (LT_LDS && !ok) ? kSentinel : eoff_lo(e);
                     const double cand = (LT_LDS || ok) ? ve0[e] + lt_e0[off] : -INFINITY;
                     if (cand > eb) ec = e;
                     eb = fmax(eb, cand);
@@ -1189,7 +1214,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #pragma unroll
                 for (int e = 0; e < H; ++e) {
                     const bool ok = e <= reach_hi;
-                    const int off = (LT_LDS && !ok) ? kSentinel : ebase_hi + e * (W - 1);
+                    const int off = (LT_LDS && !ok) ? kSentinel : eoff_hi(e);
                     const double cand = (LT_LDS || ok) ? ve0[H + e] + lt_e0[off] : -INFINITY;
                     if (cand > eb) ec = e;
                     eb = fmax(eb, cand);
@@ -1270,8 +1295,8 @@ template <int H>
 static size_t viterbi_band_lds(const PassParams &p, bool lt_lds) {
     const int B = p.n_bins, S = 2 * B;
     const int PADB = (B + 2 * H + 64 + 7) & ~7;
-    size_t b = (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16) * 16;
-    if (lt_lds) b += (size_t)4 * p.n_cls * (2 * H + 1) * 8;
+    size_t b = (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)2 * S * 2 + 15) / 16) * 16;
+    if (lt_lds) b += band_table_packed(H) ? (size_t)2 * pk_size<H>() * 8 : (size_t)4 * p.n_cls * (2 * H + 1) * 8;
     return b;
 }
 
@@ -1479,7 +1504,7 @@ hipError_t viterbi_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<25, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<50, false>),
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<50, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1521,7 +1546,7 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
                                viterbi_band_lds<25>(p, true), s, p, t, blt);
             return hipGetLastError();
         }
-        if (p.half_width == 50 && viterbi_band_lds<50>(p, false) <= 160 * 1024) {
+        if (p.half_width == 50 && t.lt_pack != nullptr && viterbi_band_lds<50>(p, true) <= 160 * 1024) {
             BandLT<50> blt;
             for (int q = 0; q < 4; ++q) {
                 std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 50) * p.width, sizeof(blt.v[q]));
@@ -1529,8 +1554,8 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
                                                 host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
             }
             blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
-            hipLaunchKernelGGL((viterbi_band_kernel<50, false>), dim3((unsigned)p.n_clips), dim3(2 * BP),
-                               viterbi_band_lds<50>(p, false), s, p, t, blt);
+            hipLaunchKernelGGL((viterbi_band_kernel<50, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
+                               viterbi_band_lds<50>(p, true), s, p, t, blt);
             return hipGetLastError();
         }
     }

@@ -175,6 +175,29 @@ std::string Tables::build(int sr_, int hop_, int n_fft_, int n_mels_, double fmi
                             std::log(sw[v][v2] * loc + DBL_MIN);
             }
         }
+        // packed copy for the LDS of the band-specialised Viterbi: blocks (0,0) == (1,1) and (0,1) == (1,0)
+        log_trans_pack.clear();
+        if (n_cls == W) {
+            bool sym = true;
+            const size_t blk = (size_t)n_cls * W;
+            for (size_t i = 0; i < blk && sym; ++i)
+                sym = log_trans_band[i] == log_trans_band[3 * blk + i] && log_trans_band[blk + i] == log_trans_band[2 * blk + i];
+            if (sym) {
+                const int NP = 3 * H * H + 3 * H + 2;
+                log_trans_pack.assign((size_t)2 * NP, log_tiny);
+                for (int q = 0; q < 2; ++q) {
+                    const double *src = log_trans_band.data() + (size_t)q * blk;     // block 0 = stay, block 1 = switch
+                    double *dst = log_trans_pack.data() + (size_t)q * NP;
+                    int o = 1;                                                       // slot 0: sentinel
+                    for (int e = 0; e < H; ++e)
+                        for (int dd = H - e; dd < W; ++dd) dst[o++] = src[(size_t)e * W + dd];
+                    for (int dd = 0; dd < W; ++dd) dst[o++] = src[(size_t)H * W + dd];
+                    for (int e = 0; e < H; ++e)
+                        for (int dd = 0; dd <= 2 * H - 1 - e; ++dd) dst[o++] = src[(size_t)(H + 1 + e) * W + dd];
+                    if (o != NP) { log_trans_pack.clear(); break; }
+                }
+            }
+        }
         freqs.resize(B);
         for (int i = 0; i < B; ++i) freqs[i] = fmin * std::pow(2.0, (double)i / (12 * bps));
     }
