@@ -139,7 +139,7 @@ __device__ __forceinline__ void fft2048(double2 *a, double2 *b, const FftTw &w, 
 //   * |XW|^2 rounded through complex64 like librosa.stft -> Slaney mel -> clip max
 // 1.5 FFTs per frame instead of 3.
 // ------------------------------------------------------------------------------------------
-constexpr int kFramePairs = 4;   // frame pairs per workgroup of frame_fft_kernel (1 for small launches: streaming pushes)
+constexpr int kFramePairs = 8;   // frame pairs per workgroup of frame_fft_kernel (1 for small launches: streaming pushes)
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
 __device__ long long g_frm_dbg[16];
 #define FRM_TICK(k) { const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
