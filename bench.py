@@ -196,6 +196,8 @@ def main():
                          # rocprofv3 --stats reports as AverageNs
                          "launches_per_step": launches, "avg_launch_ms": round(dom_ms / launches, 3),
                          "algorithmic_bytes_per_step": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds),
+                         "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds / launches),
+                         "traffic_per_launch": None if traffic is None else int(traffic / launches),
                          "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}},
             "voiced_fraction": round(voiced, 4),
         }
