@@ -216,3 +216,45 @@ def test_time_chunk_pipeline_ragged(monkeypatch):
     np.testing.assert_array_equal(ref[3]["voiced_flag"], o["voiced_flag"])
     np.testing.assert_allclose(np.nan_to_num(ref[3]["f0"]), o["f0"], rtol=1e-13)
     ref_h.close()
+
+
+def test_full_size_batch_properties():
+    """BASELINE.json configs[3] per-GPU shard at full size (64 clips x 180 s = 992 256 frames, the bench workload):
+    size-independent properties instead of an oracle run -- a clip's arrays do not depend on what else is in the
+    batch (three clips re-analysed alone, bit-identical), a second run reproduces the first, frame counts follow
+    1 + N // hop, f0 is NaN exactly where the frame is unvoiced and sits on the pitch grid elsewhere, and the
+    device-pointer entry used by bench.py agrees with the host-buffer entry."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import torch
+    clips = bench.make_clips(64, 180.0, seed0=1)
+    h = _lib.Handle()
+    a = h.analyze_batch(clips, want_sdb=False)
+    assert sum(len(r["f0"]) for r in a) == 992256 and all(len(r["f0"]) == 1 + len(c) // 512 for r, c in zip(a, clips))
+    for i in (0, 31, 63):
+        alone = h.analyze_batch([clips[i]], want_sdb=False)[0]
+        for k in alone:
+            np.testing.assert_array_equal(a[i][k], alone[k], err_msg=f"clip {i} {k}")
+    grid = h.table("freqs")
+    for i in (5, 40):
+        r = a[i]
+        assert np.array_equal(np.isnan(r["f0"]), ~r["voiced_flag"])
+        assert np.isin(r["f0"][r["voiced_flag"]], grid).all()
+        assert (r["voiced_prob"] >= 0).all() and (r["voiced_prob"] <= 1).all() and (r["rms"] >= 0).all()
+    # device-resident entry (what bench.py times)
+    dev = torch.device("cuda", 0)
+    n = np.array([len(c) for c in clips], np.int64)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    F = 992256
+    outs = {"f0": torch.empty(F, dtype=torch.float64, device=dev), "voiced_flag": torch.empty(F, dtype=torch.uint8, device=dev),
+            "voiced_prob": torch.empty(F, dtype=torch.float64, device=dev), "rms": torch.empty(F, dtype=torch.float32, device=dev),
+            "rake_mask": torch.empty(F, dtype=torch.uint8, device=dev)}
+    for _ in range(2):                                       # second pass: idempotent
+        h.analyze_batch_device(d_pcm.data_ptr(), off, {k: v.data_ptr() for k, v in outs.items()}, sync=True)
+        np.testing.assert_array_equal(outs["voiced_flag"].cpu().numpy().astype(bool), np.concatenate([r["voiced_flag"] for r in a]))
+        np.testing.assert_array_equal(outs["f0"].cpu().numpy(), np.concatenate([r["f0"] for r in a]))
+        np.testing.assert_array_equal(outs["rms"].cpu().numpy(), np.concatenate([r["rms"] for r in a]))
+        np.testing.assert_array_equal(outs["rake_mask"].cpu().numpy().astype(bool), np.concatenate([r["rake_mask"] for r in a]))
+    h.close()
