@@ -22,7 +22,10 @@ _ENGINE_ONLY_KWARGS = ("confidence_threshold", "start_time", "end_time", "turbo_
 
 
 def _require_finite(y):
-    if not np.isfinite(y).all():      # librosa.util.valid_audio raises ParameterError here
+    # librosa.util.valid_audio raises ParameterError on NaN / inf samples.  A BLAS dot product is non-finite whenever
+    # a sample is (NaN and inf propagate) and costs a quarter of np.isfinite(y).all(); only if it is non-finite --
+    # which finite samples beyond 1e19 could also cause -- is the exact test run.
+    if not np.isfinite(np.dot(y, y)) and not np.isfinite(y).all():
         raise ValueError("Audio buffer is not finite everywhere")
 
 
