@@ -2,7 +2,6 @@
 64 x 180 s through the host-buffer entry; prints wall time per batch and the hipEvent kernel times."""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
-import numpy as np
 from spectrogram_midi_amd import _lib, signals
 sr = 22050
 clips = [signals.guitar_clip(180.0, seed=1 + i % 8, sr=sr) if "sr" in signals.guitar_clip.__code__.co_varnames else None for i in range(64)]

@@ -6,7 +6,6 @@ from concurrent.futures import ProcessPoolExecutor
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ[k] = "1"
-import numpy as np
 from oracle import engine as oe
 from spectrogram_midi_amd import signals
 

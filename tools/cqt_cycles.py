@@ -1,6 +1,5 @@
 import sys, os
 sys.path.insert(0, os.getcwd())
-import numpy as np
 from spectrogram_midi_amd import _lib, signals
 clips = [signals.polyphonic_clip(30.0, seed=100 + i % 4) for i in range(64)]
 h = _lib.Handle(); h.cqt(clips[:2]); h.cqt(clips)

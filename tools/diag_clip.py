@@ -2,7 +2,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from oracle import dsp, pyin as opyin
+from oracle import pyin as opyin
 from spectrogram_midi_amd import _lib, signals
 
 rng = np.random.default_rng(0)

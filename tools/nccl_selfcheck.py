@@ -2,7 +2,6 @@
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 tools/nccl_selfcheck.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 import torch.distributed as dist
 from spectrogram_midi_amd import dist as adist
