@@ -234,33 +234,38 @@ __global__ void rsi_kernel(const double *__restrict__ x, const int64_t *__restri
     } else {
         ag = al = NAN;   // host rejects period > 128
     }
-    // one lane walks the series: the samples are fetched eight steps ahead so that the walk waits on the divisions,
-    // not on memory (the ghost-note filter calls this on a 10-per-frame density track: 77 k elements for 3 minutes)
-    constexpr int kAhead = 8;
-    double ring[kAhead];
-#pragma unroll
-    for (int k = 0; k < kAhead; ++k) ring[k] = period - 1 + k < n ? d[period - 1 + k] : 0.0;      // d[i-1+k] for i = period
-    for (int64_t i0 = period; i0 < n; i0 += kAhead) {
-        double nxt[kAhead];
-#pragma unroll
-        for (int k = 0; k < kAhead; ++k) nxt[k] = i0 - 1 + kAhead + k < n ? d[i0 - 1 + kAhead + k] : 0.0;
-#pragma unroll
-        for (int k = 0; k < kAhead; ++k) {
-            const int64_t i = i0 + k;
-            if (i >= n) break;
-            if (i > period) {
-                // gain/loss(i-1) = f(d[i] - d[i-1]); ring[k] = d[i-1], and d[i] = ring[k+1] or the next block's first
-                const double cur = k + 1 < kAhead ? ring[k + 1] : nxt[0];
-                const double dl = cur - ring[k];
-                ag = (ag * (period - 1) + (dl > 0 ? dl : 0.0)) / period;
-                al = (al * (period - 1) + (dl < 0 ? -dl : 0.0)) / period;
-            }
-            if (al == 0) o[i] = 100;
-            else { const double rs = ag / al; o[i] = 100 - (100 / (1 + rs)); }
-        }
-#pragma unroll
-        for (int k = 0; k < kAhead; ++k) ring[k] = nxt[k];
+    // One lane walks the series.  Per element the loop-carried work is one division deep (the two Wilder averages);
+    // the RSI value itself (two more dependent divisions) hangs off it.  Blocks of eight elements without a branch
+    // inside let the scheduler run the output chains of earlier elements under the recurrence of later ones, and the
+    // samples of the next block are fetched while this one is computed (the ghost-note filter calls this on a
+    // 10-per-frame density track: 77 k elements for 3 minutes).  Same operations per element as the plain loop.
+    constexpr int K = 8;
+    const double pm1 = (double)(period - 1), pd = (double)period;
+    auto step = [&](double dl, int64_t i) {
+        ag = (ag * pm1 + (dl > 0 ? dl : 0.0)) / pd;
+        al = (al * pm1 + (dl < 0 ? -dl : 0.0)) / pd;
+        const double rs = ag / al;
+        const double val = 100 - (100 / (1 + rs));
+        o[i] = al == 0 ? 100.0 : val;
+    };
+    {   // i = period: the seed averages themselves
+        if (al == 0) o[period] = 100;
+        else { const double rs = ag / al; o[period] = 100 - (100 / (1 + rs)); }
     }
+    int64_t i = (int64_t)period + 1;                // element i uses d[i] - d[i-1]
+    double nxt[K + 1];
+#pragma unroll
+    for (int k = 0; k <= K; ++k) nxt[k] = i - 1 + k < n ? d[i - 1 + k] : 0.0;
+    for (; i + K <= n; i += K) {
+        double cur[K + 1];
+#pragma unroll
+        for (int k = 0; k <= K; ++k) cur[k] = nxt[k];
+#pragma unroll
+        for (int k = 0; k <= K; ++k) nxt[k] = i + K - 1 + k < n ? d[i + K - 1 + k] : 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) step(cur[k + 1] - cur[k], i + k);
+    }
+    for (; i < n; ++i) step(d[i] - d[i - 1], i);
 }
 
 // ---- a17: Savitzky-Golay on NaN-compacted samples (financial_filters.py:25-59) ----------------
