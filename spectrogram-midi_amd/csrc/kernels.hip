@@ -927,7 +927,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     double *valI = reinterpret_cast<double *>(smem_raw);   // [2 buf][2 v][PADB], index b + H
     double *valE = valI + 4 * PADB;                        // [2 buf][2 v][2H]
     double *rv = valE + 8 * H;                             // [2][16]  wave maxima
-    unsigned long long *omask = reinterpret_cast<unsigned long long *>(rv + 64);   // [2][16] observed-state ballots of the voiced waves (32 doubles after rv are spare)
+    double *vobs = rv + 32;                                // [2][16]  largest value among a voiced wave's observed states
+    unsigned long long *omask = reinterpret_cast<unsigned long long *>(rv + 64);   // [2][16] observed-state ballots of the voiced waves
     int *ri = reinterpret_cast<int *>(omask + 32);         // [2][16]
     uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [2][S] chunk-origin maps
     double *ltl = reinterpret_cast<double *>(
@@ -1042,7 +1043,11 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         const unsigned long long eq = __ballot(v == wm);
         if (!vp) {                     // wave-uniform
             const unsigned long long om = __ballot(obs);
+            double ov = row16_prefix_max(obs ? v : -INFINITY);
+            ov = dpp_fmax<0x142, 0xa>(ov);
+            ov = dpp_fmax<0x143, 0xc>(ov);
             if (lane == 0) omask[par * 16 + wid] = om;
+            if (lane == 63) vobs[par * 16 + wid] = ov;
         }
         if (lane == 0) {
             rv[par * 16 + wid] = wm;
@@ -1165,7 +1170,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             // vo + lmax; when that is strictly below the smallest unvoiced-chain result of the wave it can neither win
             // nor tie (a voiced candidate only beats best1 by being >= it), so the per-lane work of the entry -- table
             // lookup, add, compare, select -- is skipped on a scalar test.  94 % of the entries on the bench clips: most
-            // observed bins are sub-harmonic troughs with tiny probabilities.
+            // observed bins are sub-harmonic troughs with tiny probabilities.  The same test on the largest observed value
+            // of a voiced wave (one DPP max per voiced wave and step) skips a whole mask word without walking its bits.
             double wmin1;
             {
                 double mn = act ? -best1 : -INFINITY;      // min(best1) = -max(-best1)
@@ -1178,6 +1184,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             // observed bins within reach of this wave's targets: [wlo - H, whi + H] spans <= 3 mask words
             const int rlo = max(wlo - H, 0), rhi = min(whi + H, B - 1);
             for (int w = rlo >> 6; w <= (rhi >> 6); ++w) {
+                // the same bound for a whole mask word: no observed state of voiced wave w is worth more than vobs[w]
+                if (vobs[lpar * 16 + w] + lmax0 < wmin1) continue;
                 unsigned long long m = omask[lpar * 16 + w];
                 if (w == (rlo >> 6)) m &= ~0ull << (rlo & 63);
                 if (w == (rhi >> 6)) m &= ~0ull >> (63 - (rhi & 63));
