@@ -1070,12 +1070,25 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
     long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #endif
+    const int lrlo = max(wlo - H, 0), lrhi = min(whi + H, B - 1);
+    const int lw0 = lrlo >> 6, lw1 = lrhi >> 6;
     int cur = 0;
     for (int t = t_lo; t < t_hi; ++t) {
         VIT_TICK(5)
         double lp = 0.0;
         if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
         const int lpar = par ^ 1;      // parity the previous end_of_step wrote its lists under
+        // observed bins within reach of this wave's targets, [wlo - H, whi + H], span <= 3 mask words: their masks and
+        // the voiced waves' largest observed values are fetched here, far ahead of the list section that tests them
+        double vb[3];
+        unsigned long long mk[3];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int wv = lw0 + u;
+            const bool okw = LT_LDS && wv <= lw1;
+            vb[u] = okw ? vobs[lpar * 16 + wv] : -INFINITY;
+            mk[u] = okw ? omask[lpar * 16 + wv] : 0ull;
+        }
 
         const double *vi0 = valI + (cur * 2 + 0) * PADB + b2c;
         const double *vi1 = valI + (cur * 2 + 1) * PADB + b2c;
@@ -1181,14 +1194,14 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
                 wmin1 = -read_lane_f64(mn, 63);
             }
             const double lmax0 = blt.lmax[0 * 2 + vp];
-            // observed bins within reach of this wave's targets: [wlo - H, whi + H] spans <= 3 mask words
-            const int rlo = max(wlo - H, 0), rhi = min(whi + H, B - 1);
-            for (int w = rlo >> 6; w <= (rhi >> 6); ++w) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int w = lw0 + u;
                 // the same bound for a whole mask word: no observed state of voiced wave w is worth more than vobs[w]
-                if (vobs[lpar * 16 + w] + lmax0 < wmin1) continue;
-                unsigned long long m = omask[lpar * 16 + w];
-                if (w == (rlo >> 6)) m &= ~0ull << (rlo & 63);
-                if (w == (rhi >> 6)) m &= ~0ull >> (63 - (rhi & 63));
+                if (vb[u] + lmax0 < wmin1) continue;
+                unsigned long long m = mk[u];
+                if (w == lw0) m &= ~0ull << (lrlo & 63);
+                if (w == lw1) m &= ~0ull >> (63 - (lrhi & 63));
                 m = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
                     (unsigned)__builtin_amdgcn_readfirstlane((int)m);
                 while (m) {                                  // ascending bins: strict '>' keeps the lowest index
