@@ -952,8 +952,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 
     // Issue priority by expected work: the step ends when the slowest wave reaches the barrier, and the SIMD arbiter
     // otherwise serves the oldest wave first.  Edge waves (25 or 50 extra candidates per source voicing) first, then
-    // the low-bin waves (most observed sources: sub-harmonic troughs crowd the low bins), then the other
-    // rest (a separate, lower level for the voiced-target interior waves starved them: +2 %); measured 76.3 -> 72.5 ms
+    // the low-bin waves (most observed sources: sub-harmonic troughs crowd the low bins), then the rest
+    // (a separate, lower level for the voiced-target interior waves starved them: +2 %); measured 76.3 -> 72.5 ms
     // when introduced.  Priorities by list length per step cost more than they gain.
     if (wave_low || wave_high) __builtin_amdgcn_s_setprio(3);
     else if (wlo < 128) __builtin_amdgcn_s_setprio(2);
