@@ -46,6 +46,7 @@ struct aegis_handle {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
+    hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
     hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
@@ -224,6 +225,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
+    CRTHIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
     if (const char *e = std::getenv("AEGIS_TIME_CHUNK")) {
         const long v = std::strtol(e, nullptr, 10);
         if (v >= 64 && v % kViterbiChunk == 0) h->time_chunk = v;
@@ -265,6 +267,7 @@ void aegis_destroy(aegis_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+    if (h->stream4) (void)hipStreamSynchronize(h->stream4);
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
@@ -277,6 +280,7 @@ void aegis_destroy(aegis_handle *h) {
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
+    if (h->stream4) (void)hipStreamDestroy(h->stream4);
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
     delete h;
 }
@@ -467,12 +471,21 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipMemcpyAsync(h->sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, s));
         p.vstate = static_cast<double *>(h->vstate.p);
         hipStream_t sv = (nk > 1) ? h->stream2 : s;
-        while ((int)h->sync_events.size() < nk + 1) {
+        // Large batches are frame-stage bound (every CU carries a Viterbi workgroup): alternating the chunks over two
+        // streams lets chunk k+1's FFTs overlap chunk k's latency-bound YIN / observation kernels (256 clips: 273 -> 259 ms).
+        // Small batches are Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream.
+        const bool two_fs = py && nk > 2 && nc >= 128;
+        while ((int)h->sync_events.size() < nk + 3) {
             hipEvent_t e;
             HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             h->sync_events.push_back(e);
         }
+        if (two_fs) {      // everything enqueued on s so far (metadata copies) precedes the second frame stream
+            HIPCHK(h, hipEventRecord(h->sync_events[nk + 1], s));
+            HIPCHK(h, hipStreamWaitEvent(h->stream4, h->sync_events[nk + 1], 0));
+        }
         for (int k = 0; k < nk; ++k) {
+            hipStream_t fs = (two_fs && (k & 1)) ? h->stream4 : s;
             p.sel_off = static_cast<const int64_t *>(h->sel_off.p) + (size_t)k * (nc + 1);
             p.t_begin = chunk_lo(k);
             p.n_sel = m.sel_off[(size_t)k * (nc + 1) + nc];
@@ -494,15 +507,15 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 }
                 if (any) {
                     HIPCHK(h, hipEventRecord(h->copy_event, h->stream3));
-                    HIPCHK(h, hipStreamWaitEvent(s, h->copy_event, 0));
+                    HIPCHK(h, hipStreamWaitEvent(fs, h->copy_event, 0));
                 }
             }
-            begin_event(h, "frame_fft", s); launch_frame_fft(p, h->dt, s); end_event(h, s);
+            begin_event(h, "frame_fft", fs); launch_frame_fft(p, h->dt, fs); end_event(h, fs);
             if (py) {
-                begin_event(h, "yin_seq", s); launch_yin_seq(p, h->dt, s); end_event(h, s);
-                begin_event(h, "pyin_obs", s); launch_pyin_obs(p, h->dt, s); end_event(h, s);
+                begin_event(h, "yin_seq", fs); launch_yin_seq(p, h->dt, fs); end_event(h, fs);
+                begin_event(h, "pyin_obs", fs); launch_pyin_obs(p, h->dt, fs); end_event(h, fs);
                 if (nk > 1) {
-                    HIPCHK(h, hipEventRecord(h->sync_events[k], s));
+                    HIPCHK(h, hipEventRecord(h->sync_events[k], fs));
                     HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[k], 0));
                 }
                 begin_event(h, "viterbi", sv);
@@ -510,6 +523,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 end_event(h, sv);
                 if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
             }
+        }
+        if (two_fs) {      // the dB / rake finalisation needs every chunk's mel rows and clip maxima
+            HIPCHK(h, hipEventRecord(h->sync_events[nk + 2], h->stream4));
+            HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[nk + 2], 0));
         }
         begin_event(h, "finalize", s); launch_finalize_mel(p, h->dt, s); end_event(h, s);
         if (py) {

@@ -258,3 +258,23 @@ def test_full_size_batch_properties():
         np.testing.assert_array_equal(outs["rms"].cpu().numpy(), np.concatenate([r["rms"] for r in a]))
         np.testing.assert_array_equal(outs["rake_mask"].cpu().numpy().astype(bool), np.concatenate([r["rake_mask"] for r in a]))
     h.close()
+
+
+def test_two_frame_streams_large_batch(monkeypatch):
+    """Passes of >= 128 clips alternate their time chunks' frame stage over two streams (chunk k+1's FFTs under chunk
+    k's YIN / observation kernels).  With AEGIS_TIME_CHUNK=64 a batch of 130 short ragged clips runs that path; the
+    default handle analyses the same clips without chunking.  Bit-identical."""
+    rng = np.random.default_rng(3)
+    base = signals.guitar_clip(8.0, seed=21)
+    clips = [base[o:o + n].copy() for o, n in zip(rng.integers(0, 150000, 130), rng.integers(30000, 190000, 130))]
+    clips[7] = np.zeros(0, np.float32)
+    ref_h = _lib.Handle()
+    ref = ref_h.analyze_batch(clips)
+    monkeypatch.setenv("AEGIS_TIME_CHUNK", "64")
+    h = _lib.Handle()
+    got = h.analyze_batch(clips)
+    monkeypatch.delenv("AEGIS_TIME_CHUNK")
+    for i in range(len(clips)):
+        for k in ref[i]:
+            np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"clip {i} {k}")
+    h.close(); ref_h.close()
