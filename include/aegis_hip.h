@@ -171,7 +171,9 @@ int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *off
 /* Host-side copies of the tables the kernels use.  `name` is one of
  * "hann" f64[n_fft], "mel_dense" f32[n_mels*(1+n_fft/2)], "thresholds" f64[101],
  * "beta_probs" f64[100], "beta_cumsum" f64[101], "boltz_fact" f64[n], "boltz_exp" f64[n],
- * "log_trans_band" f64[4*n_cls*width], "freqs" f64[n_pitch_bins], "twiddle" f64[2*n_fft].
+ * "log_trans_band" f64[4*n_cls*width], "log_trans_pack" f64[2*(3H^2+3H+2)] (H = (width-1)/2: the band table
+ * without its duplicate (v,v') blocks and unreachable edge-row entries, as the Viterbi kernel keeps it in LDS),
+ * "freqs" f64[n_pitch_bins], "twiddle" f64[2*n_fft].
  * Returns the element count (or a negative code); copies min(count, cap) elements. */
 int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int64_t cap);
 

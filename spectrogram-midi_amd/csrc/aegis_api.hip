@@ -1126,6 +1126,7 @@ int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int6
     else if (n == "boltz_fact") setd(t.boltz_fact);
     else if (n == "boltz_exp") setd(t.boltz_exp);
     else if (n == "log_trans_band") setd(t.log_trans_band);
+    else if (n == "log_trans_pack") setd(t.log_trans_pack);
     else if (n == "freqs") setd(t.freqs);
     else if (n == "twiddle") setd(t.twiddle);
     else if (n == "mel_dense") { src = t.mel_dense.data(); count = (int64_t)t.mel_dense.size(); esz = 4; }

@@ -95,6 +95,31 @@ def test_banded_transition_table(host_handle):
     assert LT[0, 200] == np.log(opyin.TINY)
 
 
+@pytest.mark.parametrize("sr,H", [(44100, 25), (22050, 50)])
+def test_packed_transition_table(sr, H):
+    """The LDS copy of the band table (csrc/kernels.hip pk_*): blocks (0,0) == (1,1) and (0,1) == (1,0) are stored once,
+    edge rows only over the targets that exist.  Every entry of the full table must be found at its packed index."""
+    h = _lib.Handle(sample_rate=sr, device=-1)
+    W, B = 2 * H + 1, 441
+    assert h.param("transition_width") == W
+    full = h.table("log_trans_band").reshape(4, W, W)
+    np.testing.assert_array_equal(full[0], full[3])
+    np.testing.assert_array_equal(full[1], full[2])
+    NP = 3 * H * H + 3 * H + 2
+    pack = h.table("log_trans_pack").reshape(2, NP)
+    lo_start = lambda e: 1 + e * (H + 1) + e * (e - 1) // 2
+    int_start = 1 + H * (H + 1) + H * (H - 1) // 2
+    hi_start = lambda e: int_start + W + 2 * H * e - e * (e - 1) // 2
+    assert hi_start(H) == NP
+    for q in range(2):
+        for e in range(H):                                   # source bin e: targets 0 .. e+H  <=>  dd = H-e .. 2H
+            np.testing.assert_array_equal(pack[q, lo_start(e):lo_start(e) + H + 1 + e], full[q, e, H - e:])
+            # source bin B-H+e (class H+1+e): targets .. B-1  <=>  dd = 0 .. 2H-1-e
+            np.testing.assert_array_equal(pack[q, hi_start(e):hi_start(e) + 2 * H - e], full[q, H + 1 + e, :2 * H - e])
+        np.testing.assert_array_equal(pack[q, int_start:int_start + W], full[q, H])
+    h.close()
+
+
 def test_other_configuration_and_rejections():
     h = _lib.Handle(sample_rate=22050, device=-1)
     assert (h.param("min_period"), h.param("max_period"), h.param("transition_width")) == (21, 268, 101)
@@ -119,3 +144,21 @@ def test_product_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), fn
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    """profiles/r1_e_bench.json is bench.py's own output on the MI355X: metric / value / n_gpus / steps / warmup /
+    ms_per_step / scaling / dtype / data / config.workload plus the roofline and cpu_baseline objects."""
+    import json, os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_e_bench.json")
+    d = json.load(open(p))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["unit"] == "GB/s"
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert abs(d["value"] - 64 * 180 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
