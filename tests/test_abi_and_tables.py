@@ -162,3 +162,29 @@ def test_committed_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
     assert abs(d["value"] - 64 * 180 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+
+
+def _build_c_demo(tmp_path):
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "aegis_demo")
+    libdir = os.path.join(root, "spectrogram-midi_amd")
+    subprocess.run(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"),
+                    os.path.join(root, "examples", "aegis_demo.c"), "-o", exe, "-L" + libdir, "-l:libaegis_hip.so",
+                    "-Wl,-rpath," + libdir, "-lm"], check=True, capture_output=True)
+    return exe
+
+
+def test_c_abi_example_compiles_and_links(tmp_path):
+    """The boundary is a C ABI: examples/aegis_demo.c (plain C99, no Python, no torch) must build against
+    include/aegis_hip.h and link against the shared library."""
+    import os
+    assert os.path.exists(_build_c_demo(tmp_path))
+
+
+@pytest.mark.gpu
+def test_c_abi_example_runs(tmp_path):
+    import subprocess
+    r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "on the 220.00 Hz grid point" in r.stdout
