@@ -27,8 +27,13 @@ PARITY PIN STATUS
   the reference -- `tests/golden/make_v2_golden.py` imports those NumPy/SciPy-only modules and freezes
   their outputs (`v2_trend_golden.npz`, `v2_harmonic_golden.json`); no restatement stands in between.
   Only `detect_slides_macd` needed a one-formula `librosa.hz_to_midi` stub.
-* `oracle.events` / `oracle.smf` (reference `aegis_engine_core/midi_logic.py`,
-  `aegis_engine.py:98-179`; mido un-vendored): unpinned for the same reason;
+* `oracle.events` (reference `aegis_engine_core/midi_logic.py:6-148`): PINNED.
+  `tests/golden/make_v1_events_golden.py` runs the reference's own `get_midi_events` /
+  `detect_articulations` (stub `librosa` supplying hz_to_midi, amplitude_to_db and a softmask with
+  librosa's real signature; stub `mido`) on the oracle's frame arrays of four clips x four keyword sets
+  and on 40 seeded synthetic frame arrays covering every technique branch; `oracle.events` and the
+  product's `midi_logic` both reproduce `v1_events_golden.json` (tests/test_golden_v1_events.py).
+* `oracle.smf` (reference `aegis_engine.py:98-179`; mido un-vendored, not installed): unpinned;
   the SMF byte layout follows the Standard MIDI File 1.0 spec as mido 1.3
   writes it (running status inside a track, end_of_track appended).
 """

@@ -3,7 +3,7 @@
 Restates `/root/reference/aegis_engine_core/midi_logic.py:6-30`
 (`detect_articulations`) and `:32-148` (`get_midi_events`) including the quirks
 SURVEY.md section 8a lists (Q1: the softmask call always raises, so the raw f0 is
-used; Q5-Q7).  librosa helpers come from oracle.dsp.  Parity unpinned (librosa).
+used; Q5-Q7).  librosa helpers come from oracle.dsp.  PINNED by tests/golden/v1_events_golden.json (events produced by the reference module itself).
 """
 import numpy as np
 

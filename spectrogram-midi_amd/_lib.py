@@ -344,6 +344,7 @@ class Stream:
         return res
 
     def free(self):
+        # safe in either order with Handle.close(): the C handle outlives its open streams (aegis_destroy defers)
         if getattr(self, "_s", None):
             self.lib.aegis_stream_free(self._s)
             self._s = None

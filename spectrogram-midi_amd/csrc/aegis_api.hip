@@ -11,7 +11,9 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <new>
 #include <numeric>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -70,6 +72,10 @@ struct aegis_handle {
     std::map<std::string, double> last_ms;
     std::map<std::string, int> last_count;
     std::mutex mu;                            // one analyze call at a time per handle (server.py shares an engine)
+    // open aegis_stream objects keep the handle alive: aegis_destroy() with streams still open only marks the handle,
+    // the last aegis_stream_free() tears it down (either order of the two calls is safe)
+    int open_streams = 0;
+    bool destroy_requested = false;
 };
 
 // One clip fed incrementally (aegis_stream_*): its own PCM buffer and workspace, so batch calls on
@@ -178,6 +184,21 @@ void collect_events(aegis_handle *h) {
     h->last_ms["total"] = total;
 }
 
+// Nothing is thrown across the C boundary (include/aegis_hip.h): every exported entry runs its body inside
+// try { ... } catch (...) { return abi_fail(h); }, which maps the in-flight exception to a return code.
+int abi_fail(aegis_handle *h) noexcept {
+    int code = AEGIS_ERR_DEVICE;
+    const char *msg = "unknown C++ exception";
+    std::string what;
+    try { throw; }
+    catch (const std::bad_alloc &) { code = AEGIS_ERR_NOMEM; msg = "out of host memory"; }
+    catch (const std::length_error &) { code = AEGIS_ERR_NOMEM; msg = "request too large for a host container"; }
+    catch (const std::exception &e) { try { what = e.what(); msg = what.c_str(); } catch (...) {} }
+    catch (...) {}
+    try { (h ? h->err : g_create_error) = msg; } catch (...) {}
+    return code;
+}
+
 }  // namespace
 
 extern "C" {
@@ -187,6 +208,8 @@ int aegis_abi_version(void) { return AEGIS_ABI_VERSION; }
 const char *aegis_last_error(const aegis_handle *h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 int aegis_create(const aegis_config *cfg, aegis_handle **out) {
+    aegis_handle *h = nullptr;
+    try {
     if (!out) { g_create_error = "out == NULL"; return AEGIS_ERR_INVALID; }
     *out = nullptr;
     aegis_config c{};
@@ -199,7 +222,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (!(c.fmax > 0)) c.fmax = 1046.5022612023945;    // note_to_hz('C6')
     if (c.max_frames_per_pass <= 0) c.max_frames_per_pass = (int64_t)1 << 21;
 
-    auto *h = new (std::nothrow) aegis_handle();
+    h = new (std::nothrow) aegis_handle();
     if (!h) { g_create_error = "out of host memory"; return AEGIS_ERR_NOMEM; }
     const std::string terr = h->tab.build(c.sample_rate, c.hop_length, c.n_fft, c.n_mels, c.fmin, c.fmax);
     if (!terr.empty()) { g_create_error = terr; delete h; return AEGIS_ERR_INVALID; }
@@ -258,10 +281,25 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
 #undef CRTHIP
     *out = h;
     return AEGIS_OK;
+    } catch (...) {
+        const int code = abi_fail(nullptr);
+        if (h) { if (out) *out = nullptr; aegis_destroy(h); }
+        return code;
+    }
 }
+
+static void destroy_now(aegis_handle *h) noexcept;
 
 void aegis_destroy(aegis_handle *h) {
     if (!h) return;
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        if (h->open_streams > 0) { h->destroy_requested = true; return; }   // the last aegis_stream_free() finishes the job
+    }
+    destroy_now(h);
+}
+
+static void destroy_now(aegis_handle *h) noexcept {
     if (h->device < 0) { delete h; return; }
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -286,14 +324,18 @@ void aegis_destroy(aegis_handle *h) {
 }
 
 int64_t aegis_frames_for(const aegis_handle *h, int64_t n_samples) {
+    try {
     if (!h || n_samples < 0) return AEGIS_ERR_INVALID;
     return 1 + n_samples / h->tab.hop;
+    } catch (...) { return abi_fail(const_cast<aegis_handle *>(h)); }
 }
 
 int aegis_set_profiling(aegis_handle *h, int32_t on) {
+    try {
     if (!h) return AEGIS_ERR_INVALID;
     h->profiling = on != 0;
     return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
 }
 
 int aegis_last_kernel_launches(const aegis_handle *h, const char *name) {
@@ -323,9 +365,11 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
 int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                int32_t n_clips, double rake_sensitivity, uint32_t stages,
                                aegis_outputs *dout, void *stream_v, int32_t sync) {
+    try {
     if (!h) return AEGIS_ERR_INVALID;
     std::lock_guard<std::mutex> lock(h->mu);
     return analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+    } catch (...) { return abi_fail(h); }
 }
 
 static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
@@ -554,6 +598,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
 
 int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
                         double rake_sensitivity, uint32_t stages, aegis_outputs *out) {
+    try {
     if (!h) return AEGIS_ERR_INVALID;
     if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
     if (n_clips == 0) return AEGIS_OK;
@@ -595,10 +640,12 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     h->metas.clear();
     if (h->profiling) collect_events(h);
     return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
 }
 
 int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int64_t n_frames,
                         double broadband_threshold_ratio, uint8_t *mask_out) {
+    try {
     if (!h) return AEGIS_ERR_INVALID;
     if (n_mels <= 0 || n_frames < 0 || (n_frames > 0 && (!S_dB || !mask_out))) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
     if (n_frames == 0) return AEGIS_OK;
@@ -620,10 +667,12 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
     HIPCHK(h, hipMemcpyAsync(mask_out, h->io_rake.p, n_frames, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
 }
 
 int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
               int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out) {
+    try {
     if (!h) return AEGIS_ERR_INVALID;
     if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !mag_out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
     if (n_clips == 0) return AEGIS_OK;
@@ -673,6 +722,7 @@ int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples
     HIPCHK(h, hipStreamSynchronize(s));
     if (h->profiling) collect_events(h);
     return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
 }
 
 // ---- streaming -------------------------------------------------------------------------------
@@ -769,14 +819,22 @@ static int stream_run(aegis_stream *st, int64_t f_lo, int64_t f_hi, bool final_p
     return AEGIS_OK;
 }
 
-int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) {
-    if (!h || !out || max_samples <= 0) { if (h) h->err = "bad argument"; return AEGIS_ERR_INVALID; }
-    *out = nullptr;
-    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
-    std::lock_guard<std::mutex> lock(h->mu);
+// Releases everything a stream owns.  The caller holds h->mu, or the stream was never handed out.
+static void stream_release(aegis_stream *st) noexcept {
+    if (st->h && st->h->device >= 0) { (void)hipSetDevice(st->h->device); (void)hipStreamSynchronize(st->h->stream); }
+    if (st->graph_exec) (void)hipGraphExecDestroy(st->graph_exec);
+    if (st->graph) (void)hipGraphDestroy(st->graph);
+    if (st->pin_samples) (void)hipHostFree(st->pin_samples);
+    if (st->pin_result) (void)hipHostFree(st->pin_result);
+    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->acf, &st->yin, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
+                      &st->live, &st->melpow, &st->clipmax, &st->rake_raw, &st->vstate, &st->meta, &st->o_f0, &st->o_voiced,
+                      &st->o_vprob, &st->o_rms, &st->o_rake, &st->o_sdb})
+        free_buf(*b);
+    delete st;
+}
+
+static int stream_open_locked(aegis_handle *h, int64_t max_samples, aegis_stream *st) {
     HIPCHK(h, hipSetDevice(h->device));
-    auto *st = new (std::nothrow) aegis_stream();
-    if (!st) { h->err = "out of host memory"; return AEGIS_ERR_NOMEM; }
     st->h = h;
     const Tables &t = h->tab;
     st->cap_samples = max_samples;
@@ -792,7 +850,7 @@ int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) 
     need(st->meta, 9 * 8); need(st->ctl, sizeof(StreamCtl)); need(st->g_staging, 8192 * 4); need(st->g_result, 256);
     need(st->o_f0, F * 8); need(st->o_voiced, F); need(st->o_vprob, F * 8); need(st->o_rms, F * 4); need(st->o_rake, F);
     need(st->o_sdb, F * t.n_mels * 4);
-    if (rc != AEGIS_OK) { aegis_stream_free(st); return rc; }
+    if (rc != AEGIS_OK) return rc;
     HIPCHK(h, hipMemsetAsync(st->clipmax.p, 0, 16, h->stream));
     {
         StreamCtl c0{};
@@ -803,31 +861,56 @@ int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) 
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (hipHostMalloc(reinterpret_cast<void **>(&st->pin_samples), 8192 * 4, hipHostMallocDefault) != hipSuccess) st->pin_samples = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&st->pin_result), 256, hipHostMallocDefault) != hipSuccess) st->pin_result = nullptr;
+    // AEGIS_STREAM_GRAPH=0 keeps every push on the plain-launch path (isolates the hipGraph replay when profiling)
+    if (const char *e = std::getenv("AEGIS_STREAM_GRAPH")) st->graph_failed = (e[0] == '0');
+    return AEGIS_OK;
+}
+
+int aegis_stream_open(aegis_handle *h, int64_t max_samples, aegis_stream **out) {
+    aegis_stream *st = nullptr;
+    try {
+    if (!h || !out || max_samples <= 0) { if (h) h->err = "bad argument"; return AEGIS_ERR_INVALID; }
+    *out = nullptr;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->destroy_requested) { h->err = "handle was destroyed"; return AEGIS_ERR_INVALID; }
+    st = new (std::nothrow) aegis_stream();
+    if (!st) { h->err = "out of host memory"; return AEGIS_ERR_NOMEM; }
+    const int rc = stream_open_locked(h, max_samples, st);
+    if (rc != AEGIS_OK) { stream_release(st); st = nullptr; return rc; }     // nothing leaks on a failed open
+    ++h->open_streams;
     *out = st;
     return AEGIS_OK;
+    } catch (...) {
+        const int code = abi_fail(h);
+        if (st) stream_release(st);
+        return code;
+    }
 }
 
 void aegis_stream_free(aegis_stream *st) {
     if (!st) return;
-    if (st->h && st->h->device >= 0) { (void)hipSetDevice(st->h->device); (void)hipStreamSynchronize(st->h->stream); }
-    if (st->graph_exec) (void)hipGraphExecDestroy(st->graph_exec);
-    if (st->graph) (void)hipGraphDestroy(st->graph);
-    if (st->pin_samples) (void)hipHostFree(st->pin_samples);
-    if (st->pin_result) (void)hipHostFree(st->pin_result);
-    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->acf, &st->yin, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
-                      &st->live, &st->melpow, &st->clipmax, &st->rake_raw, &st->vstate, &st->meta, &st->o_f0, &st->o_voiced,
-                      &st->o_vprob, &st->o_rms, &st->o_rake, &st->o_sdb})
-        free_buf(*b);
-    delete st;
+    aegis_handle *h = st->h;
+    if (!h) { stream_release(st); return; }
+    bool last;
+    {
+        std::lock_guard<std::mutex> lock(h->mu);
+        stream_release(st);
+        --h->open_streams;
+        last = h->destroy_requested && h->open_streams == 0;
+    }
+    if (last) destroy_now(h);     // aegis_destroy() was called while this stream was still open
 }
 
 int aegis_stream_push(aegis_stream *st, const float *samples, int64_t n, aegis_stream_frames *out, int64_t *n_frames) {
+    try {
     if (!st || !st->h) return AEGIS_ERR_INVALID;
     aegis_handle *h = st->h;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->destroy_requested) { h->err = "handle was destroyed"; return AEGIS_ERR_INVALID; }
     if (n < 0 || (n > 0 && !samples) || !n_frames) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
     if (st->closed) { h->err = "stream is closed"; return AEGIS_ERR_INVALID; }
     if (st->n_samples + n > st->cap_samples) { h->err = "stream capacity exceeded"; return AEGIS_ERR_INVALID; }
-    std::lock_guard<std::mutex> lock(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     // ---- fixed-size pushes replay a captured hipGraph ---------------------------------------------
@@ -879,14 +962,17 @@ int aegis_stream_push(aegis_stream *st, const float *samples, int64_t n, aegis_s
     }
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;
+    } catch (...) { return abi_fail((st ? st->h : nullptr)); }
 }
 
 int aegis_stream_close(aegis_stream *st, double rake_sensitivity, aegis_outputs *out, int64_t *n_frames) {
+    try {
     if (!st || !st->h) return AEGIS_ERR_INVALID;
     aegis_handle *h = st->h;
+    std::lock_guard<std::mutex> lock(h->mu);
+    if (h->destroy_requested) { h->err = "handle was destroyed"; return AEGIS_ERR_INVALID; }
     if (!n_frames) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
     if (st->closed) { h->err = "stream is closed"; return AEGIS_ERR_INVALID; }
-    std::lock_guard<std::mutex> lock(h->mu);
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     const Tables &t = h->tab;
@@ -921,10 +1007,12 @@ int aegis_stream_close(aegis_stream *st, double rake_sensitivity, aegis_outputs 
     }
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;
+    } catch (...) { return abi_fail((st ? st->h : nullptr)); }
 }
 
 int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
                 const double *params, int32_t n_params, void *const *outs, int32_t n_outs) {
+    try {
     if (!h) return AEGIS_ERR_INVALID;
     if (n_series < 0 || (n_series > 0 && (!x || !offsets)) || !outs || n_params < 0 || (n_params > 0 && !params)) {
         h->err = "bad argument"; return AEGIS_ERR_INVALID;
@@ -1049,9 +1137,11 @@ int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *off
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipStreamSynchronize(s));
     return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
 }
 
 int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64_t count) {
+    try {
     if (!h || !name || !data) return AEGIS_ERR_INVALID;
     Tables &t = h->tab;
     const std::string n(name);
@@ -1090,9 +1180,11 @@ int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64
         if ((rc = push("beta_suffix")) != AEGIS_OK) return rc;
     }
     return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
 }
 
 int64_t aegis_get_param(const aegis_handle *h, const char *name) {
+    try {
     if (!h || !name) return AEGIS_ERR_INVALID;
     const Tables &t = h->tab;
     const std::string n(name);
@@ -1108,9 +1200,11 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "obs_stride") return h->obs_stride;
     if (n == "last_frames") return h->last_frames;
     return AEGIS_ERR_INVALID;
+    } catch (...) { return abi_fail(const_cast<aegis_handle *>(h)); }
 }
 
 int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int64_t cap) {
+    try {
     if (!h || !name) return AEGIS_ERR_INVALID;
     const Tables &t = h->tab;
     const std::string n(name);
@@ -1133,11 +1227,18 @@ int64_t aegis_get_table(const aegis_handle *h, const char *name, void *dst, int6
     else return AEGIS_ERR_INVALID;
     if (dst && cap > 0) std::memcpy(dst, src, (size_t)std::min(count, cap) * esz);
     return count;
+    } catch (...) { return abi_fail(const_cast<aegis_handle *>(h)); }
 }
 
 int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t cap) {
+    try {
     if (!h || !name) return AEGIS_ERR_INVALID;
     const std::string n(name);
+    // test hooks of the exception barrier (tests/test_abi_and_tables.py): the body throws, the entry returns a code
+    if (n == "throw_bad_alloc") throw std::bad_alloc();
+    if (n == "throw_length_error") throw std::length_error("test hook");
+    if (n == "throw_runtime_error") throw std::runtime_error("test hook: runtime_error");
+    if (n == "throw_int") throw 42;
     const int64_t F = h->last_frames;
     const void *src = nullptr;
     int64_t count = 0;
@@ -1187,6 +1288,7 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
         HIPCHK(h, hipMemcpy(dst, src, (size_t)std::min(count, cap) * esz, hipMemcpyDeviceToHost));
     }
     return count;
+    } catch (...) { return abi_fail(h); }
 }
 
 }  // extern "C"

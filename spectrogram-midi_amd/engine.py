@@ -69,16 +69,28 @@ class AegisEngine:
         """aegis_engine.py:38-39 (fixed 0.6 ratio)."""
         return self.handle.rake_patterns(S_dB, 0.6)
 
+    # Pass-throughs (aegis_engine.py:29-36).  Stem separation, tab generation and MusicXML export consume file paths /
+    # the event list unchanged and are outside the MI355X path: when the reference's own package is importable (the
+    # drop-in case: this class swapped into the reference tree, INTEGRATION.md option A) the calls are forwarded to
+    # it exactly as the reference forwards them; otherwise they raise.
+    @staticmethod
+    def _reference_core(module, name):
+        import importlib
+        try:
+            return getattr(importlib.import_module(f"aegis_engine_core.{module}"), name)
+        except ImportError as e:
+            raise NotImplementedError(
+                f"{name} forwards to the reference's aegis_engine_core.{module} (aegis_engine.py:29-36), which is not "
+                f"importable here ({e}); it is outside the MI355X analyze path") from e
+
     def separate_stems(self, input_wav, output_dir):
-        raise NotImplementedError("stem separation shells out to demucs in the reference "
-                                  "(aegis_engine_core/stems.py); outside the MI355X analyze path")
+        return self._reference_core("stems", "separate_stems")(input_wav, output_dir)
 
     def generate_tabs(self, events):
-        raise NotImplementedError("tab generation (aegis_engine_core/tabs.py) consumes the event list "
-                                  "unchanged; outside the MI355X analyze path")
+        return self._reference_core("tabs", "generate_tabs")(events)
 
     def export_musicxml(self, tab_data, xml_path):
-        raise NotImplementedError("MusicXML export (aegis_engine_core/tabs.py) is outside the MI355X analyze path")
+        return self._reference_core("tabs", "export_musicxml")(tab_data, xml_path)
 
     def audio_to_midi(self, input_wav, output_mid, **kwargs):
         """Perception phase -> raw_data dict or None for empty audio (aegis_engine.py:41-75).

@@ -31,23 +31,6 @@ def karplus_strong(frequency, duration, sr=44100, decay_factor=0.996, rng=None):
     return out
 
 
-def karplus_strong_loop(frequency, duration, sr=44100, decay_factor=0.996, rng=None):
-    """Sample-by-sample form of the same recurrence (slow; used to validate the fast one)."""
-    rng = np.random.default_rng(0) if rng is None else rng
-    N = int(sr / frequency)
-    buf = rng.uniform(-1, 1, N)
-    n_samples = int(sr * duration)
-    out = np.zeros(n_samples)
-    ptr = 0
-    for i in range(n_samples):
-        val = buf[ptr]
-        out[i] = val
-        prev = buf[ptr - 1] if ptr > 0 else buf[-1]
-        buf[ptr] = 0.5 * (val + prev) * decay_factor
-        ptr = (ptr + 1) % N
-    return out
-
-
 def noise_rake(duration, sr=44100, rng=None):
     """generate_test_signal.py:44-53: N(0, 0.8) burst with a linspace(1,0)**2 envelope."""
     rng = np.random.default_rng(0) if rng is None else rng

@@ -188,3 +188,48 @@ def test_c_abi_example_runs(tmp_path):
     r = subprocess.run([_build_c_demo(tmp_path)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "on the 220.00 Hz grid point" in r.stdout
+
+
+def test_no_exception_crosses_the_c_boundary(host_handle):
+    """include/aegis_hip.h: nothing is thrown across the boundary.  Every exported body runs inside a
+    try/catch that maps the exception to a code; the debug entry's test hooks throw on purpose."""
+    import ctypes as C
+    lib, h = host_handle.lib, host_handle._h
+    for hook, code, text in ((b"throw_bad_alloc", _lib.ERR_NOMEM, "out of host memory"),
+                             (b"throw_length_error", _lib.ERR_NOMEM, "too large"),
+                             (b"throw_runtime_error", _lib.ERR_DEVICE, "test hook: runtime_error"),
+                             (b"throw_int", _lib.ERR_DEVICE, "unknown C++ exception")):
+        assert lib.aegis_debug_fetch(h, hook, None, 0) == code
+        assert text in lib.aegis_last_error(h).decode()
+    # the handle is still usable afterwards
+    assert host_handle.param("n_pitch_bins") == 441
+    # a table request the library cannot size reports a code instead of unwinding
+    cfg = _lib.Config(44100, 512, 2048, 1 << 30, 0.0, 0.0, -1, 0, 0)
+    out = C.c_void_p()
+    assert lib.aegis_create(C.byref(cfg), C.byref(out)) == _lib.ERR_INVALID and not out.value
+
+
+def test_pass_throughs_forward_to_the_reference_package(tmp_path, monkeypatch):
+    """aegis_engine.py:29-36 forward to aegis_engine_core.stems / tabs: with that package importable (the drop-in
+    case) the calls are forwarded unchanged, without it they raise NotImplementedError."""
+    import importlib
+    import sys
+    from spectrogram_midi_amd.engine import AegisEngine
+    eng = AegisEngine()
+    for mod in [m for m in sys.modules if m.split(".")[0] == "aegis_engine_core"]:
+        monkeypatch.delitem(sys.modules, mod)
+    with pytest.raises(NotImplementedError):
+        eng.generate_tabs([])
+    pkg = tmp_path / "aegis_engine_core"
+    pkg.mkdir()
+    (pkg / "__init__.py").write_text("")
+    (pkg / "tabs.py").write_text("def generate_tabs(events):\n    return ('tabs', len(events))\n"
+                                 "def export_musicxml(tab_data, path):\n    return ('xml', tab_data, path)\n")
+    (pkg / "stems.py").write_text("def separate_stems(wav, out):\n    return ('stems', wav, out)\n")
+    monkeypatch.syspath_prepend(str(tmp_path))
+    importlib.invalidate_caches()
+    assert eng.generate_tabs([1, 2, 3]) == ("tabs", 3)
+    assert eng.export_musicxml("t", "x.xml") == ("xml", "t", "x.xml")
+    assert eng.separate_stems("a.wav", "out") == ("stems", "a.wav", "out")
+    for mod in [m for m in sys.modules if m.split(".")[0] == "aegis_engine_core"]:
+        monkeypatch.delitem(sys.modules, mod)

@@ -63,3 +63,37 @@ def test_stream_edge_cases():
     np.testing.assert_array_equal(out["rms"], h.analyze_batch([np.zeros(0, np.float32)])[0]["rms"])
     empty.free()
     h.close()
+
+
+def test_graph_push_after_plain_pushes():
+    """A hop-multiple push (hipGraph replay) after odd-sized pushes (plain launches), and back: the device control
+    block and the host counters must stay in step whichever path a push takes."""
+    h = _lib.Handle()
+    y = signals.guitar_clip(5.0, seed=32)
+    ref = h.analyze_batch([y])[0]
+    _, final = run_stream(h, y, [777, 2048, 2048, 1, 2048, 1535, 2048, 2048, 2048])
+    for k in ref:
+        np.testing.assert_array_equal(final[k], ref[k], err_msg=k)
+    h.close()
+
+
+def test_graph_knob_and_lifetime_orders(monkeypatch):
+    """AEGIS_STREAM_GRAPH=0 keeps pushes on the plain-launch path (same results); a handle closed while a stream is
+    still open stays alive until that stream is freed (no use-after-free in either order)."""
+    y = signals.guitar_clip(3.0, seed=33)
+    h = _lib.Handle()
+    ref = h.analyze_batch([y])[0]
+    monkeypatch.setenv("AEGIS_STREAM_GRAPH", "0")
+    _, final = run_stream(h, y, [2048])
+    monkeypatch.delenv("AEGIS_STREAM_GRAPH")
+    for k in ref:
+        np.testing.assert_array_equal(final[k], ref[k], err_msg=k)
+    st = h.open_stream(max_seconds=1.0)
+    st.push(y[:2048])
+    h.close()                                   # aegis_destroy with a stream open: deferred
+    with pytest.raises(_lib.AegisError):
+        st.push(y[2048:4096])                   # the handle is gone as far as callers are concerned
+    st.free()                                   # last stream: tears the handle down
+    h2 = _lib.Handle()                          # the device is still usable
+    assert len(h2.analyze_batch([y[:4096]])[0]["rms"]) == 9
+    h2.close()

@@ -1,0 +1,25 @@
+"""The synthetic fixtures follow the recipe of the reference's generator (generate_test_signal.py:5-53): the
+block-wise Karplus-Strong of signals.py must satisfy the generator's sample recurrence."""
+import numpy as np
+
+from spectrogram_midi_amd import signals
+
+
+def test_karplus_strong_satisfies_the_sample_recurrence():
+    # generate_test_signal.py:22-40 reads buf[ptr], averages it with the previous (already updated) cell and writes
+    # it back scaled by the decay: y[i] = 0.5 * decay * (y[i - N] + y[i - 1]) for i >= N, the first N samples being
+    # the random excitation.
+    for freq, dur, decay in ((82.41, 0.5, 0.996), (440.0, 0.2, 0.99), (1046.5, 0.05, 0.996)):
+        y = signals.karplus_strong(freq, dur, 44100, decay_factor=decay, rng=np.random.default_rng(3))
+        N = int(44100 / freq)
+        assert len(y) == int(44100 * dur)
+        assert np.all(np.abs(y[:N]) <= 1.0)
+        want = 0.5 * decay * (y[:-N] + y[N - 1:-1])
+        np.testing.assert_allclose(y[N:], want, rtol=0, atol=1e-12)
+
+
+def test_fixture_shapes():
+    y = signals.guitar_test_track()
+    assert y.dtype == np.float32 and len(y) == 184014
+    assert abs(float(np.max(np.abs(y))) - 0.9) < 1e-6
+    assert len(signals.sine_sweep()) == 441000
