@@ -2,18 +2,25 @@
 """Throughput benchmark of the analyze hot path (BASELINE.json metric: audio-seconds
 transcribed per second, 44.1 kHz mono, n_fft=2048, hop=512).
 
-A step = one pass of the whole analyze path (mel/dB/rake + pYIN + RMS) over this rank's batch
-of synthetic clips, PCM already resident in HBM, outputs left in HBM.  Workload: the per-GPU
-shard of BASELINE.json configs[3] (512-clip folder over 8 GPUs = 64 clips per GPU) with clips
-of the configs[1] shape (3-minute 44.1 kHz mono guitar clips).  Ranks are independent (weak
-scaling, no data-path collective); rank 0 prints ONE JSON line.
+A step = one pass of the whole analyze path (mel/dB/rake + pYIN + RMS) over this rank's clips,
+PCM already resident in HBM, outputs left in HBM.  One process per GPU; rank 0 prints ONE JSON line.
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus N --steps K --warmup W          # starts the N rank processes itself
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or is started as a rank
+
+--config headline (default): the per-GPU shard of BASELINE.json configs[3] (512-clip folder over 8 GPUs = 64 clips
+    per GPU) with clips of the configs[1] shape (3-minute 44.1 kHz mono guitar clips).  Weak scaling: every rank gets
+    its own 64 clips; with N > 1 the ranks' note events are gathered over RCCL after the timed steps (reported apart).
+--config folder: configs[3] as written -- 512 seeded clips with durations U(30, 330) s (the collector's filter,
+    folder_audio_collector.py:113), one in eight polyphonic and one in eight noisy, assigned longest-first to the ranks
+    (dist.shard_clips), one ragged batch per rank, events extracted and gathered (dist.gather_events).  Strong scaling.
+--config cqt: configs[2] -- 64 x 30 s polyphonic clips through the 84-bin constant-Q filter bank (MFMA path).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,9 +34,13 @@ SR, HOP = 44100, 512
 # read the PCM once (4 B x 44100) + write the raw_data arrays
 # (f0 8 + voiced 1 + prob 8 + rms 4 + rake 1 = 22 B x 86.13 frames) per audio-second
 ALGO_BYTES_PER_AUDIO_S = 4 * SR + 22 * (SR / HOP)
-HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU x 256 CUs x 2.4 GHz)
+N_CUS = 256
+PMC_PROFILE = os.path.join("profiles", "r2_pmc_hbm.json")
 
 
+# --------------------------------------------------------------------------------------------- workloads
 def make_clips(n_clips, seconds, seed0):
     """n_clips distinct synthetic guitar clips.  Eight base clips are synthesised (Karplus-Strong
     notes + rake bursts + noise floor, signals.guitar_clip); the rest are circular shifts of them
@@ -48,57 +59,225 @@ def make_clips(n_clips, seconds, seed0):
     return clips
 
 
-def cpu_baseline(sample_seconds):
-    """Times the CPU oracle (oracle/, a NumPy restatement of the reference's librosa path with a C
-    Viterbi) on a bounded sample of the same workload, single process."""
+def folder_durations(n_clips, seed=0):
+    """Clip lengths of the synthetic folder: U(30, 330) s (folder_audio_collector.py:113 keeps 30 s < duration < 330 s)."""
+    return np.random.default_rng(seed).uniform(30.0, 330.0, n_clips)
+
+
+FOLDER_KINDS = ("guitar",) * 6 + ("polyphonic", "noisy")
+
+
+def make_folder_clips(indices, durations):
+    """The clips `indices` of the folder.  Clip i is cut, at a seeded offset and gain, from one of eight 330 s base
+    tracks chosen by i mod 8: six monophonic guitar tracks, one three-voice polyphonic track, one guitar track under a
+    -12 dBFS noise floor (where the Viterbi's exact prunes fire least)."""
+    from spectrogram_midi_amd import signals
+    kinds = sorted({i % 8 for i in indices})
+    base = {}
+    for k in kinds:
+        if FOLDER_KINDS[k] == "polyphonic":
+            base[k] = signals.polyphonic_clip(330.0, SR, seed=700 + k)
+        elif FOLDER_KINDS[k] == "noisy":
+            base[k] = signals.guitar_clip(330.0, SR, seed=700 + k, noise_dbfs=-12.0)
+        else:
+            base[k] = signals.guitar_clip(330.0, SR, seed=700 + k)
+    clips = []
+    for i in indices:
+        rng = np.random.default_rng(10_000 + i)
+        b = base[i % 8]
+        n = int(durations[i] * SR)
+        y = np.roll(b, -int(rng.integers(0, len(b))))[:n] * np.float32(rng.uniform(0.5, 1.0))
+        clips.append(np.ascontiguousarray(y, dtype=np.float32))
+    return clips
+
+
+# --------------------------------------------------------------------------------------------- CPU baseline
+def _turbo_worker_init():
+    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[k] = "1"
+
+
+def cpu_baseline(sample_seconds, turbo_seconds, turbo_cores):
+    """Times the CPU oracle (oracle/, a NumPy restatement of the reference's librosa path with a C Viterbi) on
+    bounded samples of the same workload: (A) the reference's stable single-process path, (B) its Turbo Mode
+    (aegis_engine.py:183-216: a forkserver pool of cpu_count() workers over equal time chunks of one clip)."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
     from oracle import engine as oracle_engine
     from spectrogram_midi_amd import signals
+    _turbo_worker_init()
     y = signals.guitar_clip(sample_seconds, SR, seed=1)
-    for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
-        os.environ.setdefault(k, "1")
     t0 = time.perf_counter()
     oracle_engine.audio_to_midi(y)
     dt = time.perf_counter() - t0
-    return {"value": round(sample_seconds / dt, 3), "unit": "audio-seconds/s", "cores": 1, "kind": "port",
-            "sample": f"one {sample_seconds:g} s clip of the bench workload (signals.guitar_clip seed 1), "
-                      f"oracle.engine.audio_to_midi stable path, {dt:.1f} s wall",
-            "host_cpus": os.cpu_count()}
+    out = {"value": round(sample_seconds / dt, 3), "unit": "audio-seconds/s", "cores": 1, "kind": "port",
+           "sample": f"(A) stable path: one {sample_seconds:g} s clip of the bench workload (signals.guitar_clip seed 1), "
+                     f"oracle.engine.audio_to_midi, {dt:.1f} s wall",
+           "host_cpus": os.cpu_count()}
+    if turbo_seconds > 0:
+        cores = turbo_cores or os.cpu_count()
+        yt = signals.guitar_clip(turbo_seconds, SR, seed=1)
+        try:
+            with ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("forkserver"),
+                                     initializer=_turbo_worker_init) as pool:
+                list(pool.map(abs, range(cores)))         # warm pool (the reference pays the start-up in every call)
+                t0 = time.perf_counter()
+                oracle_engine.audio_to_midi(yt, turbo_mode=True, num_cores=cores, pool=pool)
+                dtt = time.perf_counter() - t0
+            out["turbo"] = {"value": round(turbo_seconds / dtt, 3), "unit": "audio-seconds/s", "cores": cores,
+                            "sample": f"(B) Turbo Mode: one {turbo_seconds:g} s clip cut into {cores} time chunks over a warm "
+                                      f"forkserver pool of {cores} workers, {dtt:.1f} s wall"}
+        except Exception as e:      # a sandbox without forkserver must not lose the GPU line
+            out["turbo"] = {"value": None, "error": repr(e)}
+    return out
 
 
-def measured_traffic(kernel, args):
-    """HBM bytes per step of `kernel` from the committed rocprofv3 --pmc passes (profiles/
-    r1_pmc_hbm.json: FETCH_SIZE and WRITE_SIZE in KB, summed over the launches of one step;
-    FETCH_SIZE doubled per MI355X_MICROARCH.md, HBM section).  Only valid for the default workload."""
-    path = os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")
-    if args.clips != 64 or args.clip_seconds != 180.0 or not os.path.exists(path):
+def measured_traffic(kernel, default_workload):
+    """HBM bytes per step of `kernel` from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE and
+    WRITE_SIZE in KB summed over one step's launches, FETCH_SIZE doubled per MI355X_MICROARCH.md).  A constant read
+    from the repository, not observed in this run: flagged `traffic_static`."""
+    path = os.path.join(ROOT, PMC_PROFILE)
+    if not default_workload or not os.path.exists(path):
         return None, None
     with open(path) as f:
         pmc = json.load(f)
     rec = pmc.get("per_step", {}).get(kernel)
     if not rec:
         return None, None
-    return int((2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024), "profiles/r1_pmc_hbm.json"
+    return int((2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024), PMC_PROFILE
 
 
-def main():
+# --------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N rank processes from here.  This parent never touches
+    the GPU (no torch import, no HIP call) -- the ranks are fresh child processes, one per device."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(n))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:           # one rank failed: the others would wait at the barrier for ever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# --------------------------------------------------------------------------------------------- one rank
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--clips", type=int, default=64, help="clips per GPU")
+    ap.add_argument("--config", choices=("headline", "folder", "cqt"), default="headline")
+    ap.add_argument("--clips", type=int, default=64, help="headline: clips per GPU")
     ap.add_argument("--clip-seconds", type=float, default=180.0)
-    ap.add_argument("--cpu-sample-seconds", type=float, default=240.0, help="oracle sample (about 15 s of CPU work)")
+    ap.add_argument("--folder-clips", type=int, default=512, help="folder: clips in the whole folder")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=240.0, help="oracle sample (A), about 15 s of CPU work")
+    ap.add_argument("--cpu-turbo-seconds", type=float, default=120.0, help="oracle sample (B) Turbo Mode; 0 skips it")
+    ap.add_argument("--cpu-turbo-cores", type=int, default=0, help="Turbo pool size; 0 = os.cpu_count() like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test hook: every rank uses cuda:0 and the gloo backend (multi-rank path on a 1-GPU box)")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+def run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum):
+    """configs[2]: 64 x 30 s polyphonic clips through aegis_cqt (84 bins, block-sparse f32 MFMA GEMM).  The entry takes
+    host PCM; `value` comes from the kernel's own HIP-event time (inputs resident in HBM), the host-inclusive wall time
+    is reported beside it."""
+    import torch
+    from spectrogram_midi_amd import _lib, signals
+    clips = [signals.polyphonic_clip(30.0, SR, seed=100 + 64 * rank + i) for i in range(8)]
+    rng = np.random.default_rng(rank)
+    while len(clips) < 64:
+        b = clips[len(clips) % 8]
+        clips.append((np.roll(b, int(rng.integers(1, len(b)))) * np.float32(rng.uniform(0.5, 1.0))).astype(np.float32))
+    handle = _lib.Handle(sample_rate=SR, hop_length=HOP, device=dev.index)
+    audio_seconds = sum(len(c) for c in clips) / SR
+    frames = sum(handle.frames_for(len(c)) for c in clips)
+    for _ in range(args.warmup):
+        handle.cqt(clips)
+    handle.set_profiling(True)
+    kms = 0.0
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        handle.cqt(clips)
+        kms += handle.kernel_ms("cqt")
+    fence()
+    wall = time.perf_counter() - t0
+    kernel_s = reduce_max(kms * 1e-3)
+    wall = reduce_max(wall)
+    total_audio = reduce_sum(audio_seconds)
+    if rank != 0:
+        return None
+    # issued MFMA work: per-tile half supports exactly as csrc/cqt.hip::build_cqt_bank derives them (512-sample
+    # granularity), one 16x16x4 f32 MFMA (2048 flop) per 4 taps, 16 rows and 16 frames; 48 frames (3 column tiles)
+    # per workgroup.  Useful work: re + im multiply-add per tap of each bin's own support and frame.
+    r = 2.0 ** (1 / 12)
+    alpha = (r * r - 1) / (r * r + 1)
+    ilen = [(1.0 / alpha) * SR / (32.70319566257483 * 2.0 ** (k / 12)) for k in range(84)]
+    half = [(int(-np.floor(-ilen[8 * T] / 2)) + 1 + 511) // 512 * 512 for T in range(11)]
+    ksteps = sum(2 * x // 4 for x in half)
+    col_tiles = 3 * sum(-(-handle.frames_for(len(c)) // 48) for c in clips)
+    issued = ksteps * 2048.0 * col_tiles
+    useful = 4.0 * sum(ilen) * frames
+    per_launch_s = kernel_s / args.steps
+    return {
+        "metric": "audio-seconds through the 84-bin CQT filter bank/sec (44.1 kHz, hop=512)",
+        "value": round(total_audio * args.steps / kernel_s, 2), "unit": "audio-seconds/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_launch_s * 1e3, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[2]: 64 x 30 s polyphonic clips (3 Karplus-Strong voices), CQT C1 + 84 bins, 12 per octave",
+                   "clips_per_gpu": 64, "clip_seconds": 30.0, "sample_rate": SR, "hop_length": HOP, "frames_per_gpu": frames,
+                   "timed": "cqt_slide_kernel by HIP events on the handle's stream; host-inclusive wall beside it"},
+        "roofline": {"bound": "mfma", "kernel": "cqt_slide", "achieved": round(issued / per_launch_s / 1e12, 2),
+                     "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / per_launch_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                     "frac_useful": round(useful / per_launch_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+                     "issued_flop_per_launch": int(issued), "useful_flop_per_launch": int(useful), "traffic": None},
+        "host_inclusive_ms_per_step": round(wall / args.steps * 1e3, 3),
+    }
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(env_world or "1")
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's process count and "
+                         "--gpus must agree (a line claiming the wrong n_gpus would be worthless)")
 
     import torch
     import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the analyze path has no CPU fallback")
     if args.rehearse_on_one_gpu:
@@ -113,17 +292,61 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from spectrogram_midi_amd import _lib
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
 
-    clips = make_clips(args.clips, args.clip_seconds, seed0=1000 * rank + 1)
+    def reduce(x, op):
+        if world == 1:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=op)
+        return float(t.item())
+
+    reduce_max = lambda x: reduce(x, dist.ReduceOp.MAX)
+    reduce_sum = lambda x: reduce(x, dist.ReduceOp.SUM)
+
+    def gather_floats(x):
+        if world == 1:
+            return [float(x)]
+        out = [torch.zeros(1, dtype=torch.float64, device=red_dev) for _ in range(world)]
+        dist.all_gather(out, torch.tensor([x], dtype=torch.float64, device=red_dev))
+        return [float(t.item()) for t in out]
+
+    def finish(line):
+        if rank == 0 and line is not None:
+            print(json.dumps(line), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    if args.config == "cqt":
+        return finish(run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum))
+
+    from spectrogram_midi_amd import _lib, dist as adist, midi_logic
+
+    # ---- this rank's clips ---------------------------------------------------------------------------
+    if args.config == "folder":
+        durations = folder_durations(args.folder_clips)
+        shards = adist.shard_clips(durations, world)
+        mine = shards[rank]
+        clips = make_folder_clips(mine, durations)
+        clip_ids = list(mine)
+    else:
+        clips = make_clips(args.clips, args.clip_seconds, seed0=1000 * rank + 1)
+        clip_ids = [rank * args.clips + i for i in range(len(clips))]
     n_samples = np.array([len(c) for c in clips], dtype=np.int64)
     offsets = np.concatenate([[0], np.cumsum(n_samples)]).astype(np.int64)
     audio_seconds = float(n_samples.sum()) / SR
+    total_frames = int((n_samples // HOP + 1).sum())
     handle = _lib.Handle(sample_rate=SR, hop_length=HOP, device=local_rank,
-                         max_frames_per_pass=max(1 << 21, int(n_samples.sum() // HOP + len(n_samples) + 1)))
-    frames = int(sum(handle.frames_for(int(n)) for n in n_samples))
+                         max_frames_per_pass=(1 << 21) if args.config == "folder" else max(1 << 21, total_frames))
+    frame_counts = [handle.frames_for(int(n)) for n in n_samples]
+    frames = int(sum(frame_counts))
 
-    d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    d_pcm = torch.from_numpy(np.concatenate(clips) if clips else np.zeros(1, np.float32)).to(dev)
     d_out = {
         "f0": torch.empty(frames, dtype=torch.float64, device=dev),
         "voiced_flag": torch.empty(frames, dtype=torch.uint8, device=dev),
@@ -138,59 +361,93 @@ def main():
         handle.analyze_batch_device(d_pcm.data_ptr(), offsets, out_ptrs, rake_sensitivity=0.6,
                                     stages=_lib.STAGE_ALL, sync=True)
 
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     for _ in range(args.warmup):
         step()
     handle.set_profiling(True)
+    handle.viterbi_stats(reset=True)
     kernel_ms, kernel_n = {}, {}
+    KERNELS = ("frame_fft", "yin_seq", "pyin_obs", "viterbi", "finalize")
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-        for k in ("frame_fft", "yin_seq", "pyin_obs", "viterbi", "finalize"):
-            kernel_ms[k] = kernel_ms.get(k, 0.0) + handle.kernel_ms(k)
-            kernel_n[k] = kernel_n.get(k, 0) + handle.kernel_launches(k)
+        for k in KERNELS:
+            ms = handle.kernel_ms(k)
+            if ms >= 0:
+                kernel_ms[k] = kernel_ms.get(k, 0.0) + ms
+                kernel_n[k] = kernel_n.get(k, 0) + handle.kernel_launches(k)
+    busy = time.perf_counter() - t0          # this rank's own time, before it waits for the others
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([audio_seconds], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_audio = float(tot.item())
-    else:
-        total_audio = audio_seconds
+    vstats = handle.viterbi_stats(reset=True)
+    elapsed = reduce_max(elapsed)
+    total_audio = reduce_sum(audio_seconds)
+    rank_busy_ms = [round(b / args.steps * 1e3, 3) for b in gather_floats(busy)]
+    rank_audio = [round(a, 1) for a in gather_floats(audio_seconds)]
 
+    # ---- note events of this rank's clips, gathered on rank 0 (the only exchange of the job) -----------
+    t0 = time.perf_counter()
+    host = {k: v.cpu().numpy() for k, v in d_out.items()}
+    rows, fo = [], 0
+    for cid, Fc in zip(clip_ids, frame_counts):
+        sl = slice(fo, fo + Fc)
+        ev = midi_logic.get_midi_events(rake_mask=host["rake_mask"][sl].astype(bool), f0=np.nan_to_num(host["f0"][sl]),
+                                        voiced_flag=host["voiced_flag"][sl].astype(bool), active_probs=host["voiced_prob"][sl],
+                                        rms=host["rms"][sl], sr=SR, hop_length=HOP, confidence_threshold=0.70)
+        rows.append(adist.pack_events(cid, ev))
+        fo += Fc
+    local_rows = np.concatenate(rows) if rows else np.zeros((0, 10))
+    events_ms = (time.perf_counter() - t0) * 1e3
+    gather_ms, n_events = None, int(local_rows.shape[0])
+    if world > 1:
+        fence()
+        t0 = time.perf_counter()
+        gathered = adist.gather_events(local_rows, dst=0, device=red_dev)
+        fence()
+        gather_ms = (time.perf_counter() - t0) * 1e3
+        if rank == 0:
+            n_events = int(gathered.shape[0])
+            assert len(set(gathered[:, 0].astype(int))) <= (args.folder_clips if args.config == "folder" else world * args.clips)
+    events_ms = reduce_max(events_ms)
+
+    line = None
     if rank == 0:
         kernel_ms = {k: v / args.steps for k, v in kernel_ms.items()}
         dom = max(kernel_ms, key=kernel_ms.get)
         dom_ms = kernel_ms[dom]
         achieved = ALGO_BYTES_PER_AUDIO_S * audio_seconds / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         launches = max(1, kernel_n.get(dom, 0) // max(1, args.steps))
-        traffic, traffic_src = measured_traffic(dom, args)
+        default_workload = args.config == "headline" and args.clips == 64 and args.clip_seconds == 180.0
+        traffic, traffic_src = measured_traffic(dom, default_workload)
         voiced = float(d_out["voiced_flag"].float().mean().item())
+        if args.config == "folder":
+            workload = (f"configs[3] as written: folder of {args.folder_clips} clips, durations U(30,330) s (1/8 polyphonic, 1/8 noisy), "
+                        f"longest-first shard over {world} GPU(s), one ragged batch per rank, events gathered on rank 0")
+            cfg = {"workload": workload, "folder_clips": args.folder_clips, "clips_on_rank0": len(clip_ids),
+                   "folder_audio_seconds": round(total_audio, 1)}
+            scaling = "strong"
+        else:
+            workload = (f"configs[3] per-GPU shard: {args.clips} clips x {args.clip_seconds:g} s "
+                        "(configs[1] clip shape), full mel/dB/rake + pYIN + RMS")
+            cfg = {"workload": workload, "clips_per_gpu": args.clips, "clip_seconds": args.clip_seconds}
+            scaling = "weak"
+        cfg.update({"sample_rate": SR, "n_fft": 2048, "hop_length": HOP, "frames_on_rank0": frames,
+                    "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path; "
+                                   "packed note events all_gathered at the end (RCCL)"})
+        # one Viterbi workgroup per clip: the dominant kernel's share of the chip is set by the clips in flight
+        clips_in_flight = min(len(clip_ids), N_CUS)
         line = {
             "metric": "audio-seconds transcribed/sec (44.1 kHz, n_fft=2048)",
             "value": round(total_audio * args.steps / elapsed, 2),
             "unit": "audio-seconds/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"configs[3] per-GPU shard: {args.clips} clips x {args.clip_seconds:g} s "
-                                   "(configs[1] clip shape), full mel/dB/rake + pYIN + RMS",
-                       "clips_per_gpu": args.clips, "clip_seconds": args.clip_seconds, "sample_rate": SR,
-                       "n_fft": 2048, "hop_length": HOP, "frames_per_gpu": frames,
-                       "parallelism": f"clips sharded over {world} GPU(s), no collective on the data path"},
+            "config": cfg,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_source": traffic_src,
+                         "traffic_static": traffic is not None, "traffic_source": traffic_src,
                          # the time-chunked pipeline launches the kernel once per time chunk: bytes and
                          # duration below are per step (= sum over those launches); avg_launch_ms is what
                          # rocprofv3 --stats reports as AverageNs
@@ -198,15 +455,20 @@ def main():
                          "algorithmic_bytes_per_step": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds),
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds / launches),
                          "traffic_per_launch": None if traffic is None else int(traffic / launches),
+                         # why the HBM fraction is small: the time-sequential Viterbi occupies one CU per clip
+                         "cus_busy_fraction": round(clips_in_flight / N_CUS, 4) if dom == "viterbi" else 1.0,
                          "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}},
             "voiced_fraction": round(voiced, 4),
+            "rank_busy_ms": rank_busy_ms, "rank_audio_seconds": rank_audio,
+            "events": {"count": n_events, "extract_ms": round(events_ms, 2),
+                       "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                       "backend": None if world == 1 else ("gloo" if args.rehearse_on_one_gpu else "nccl (RCCL)")},
         }
+        if vstats is not None and vstats["wave_steps"] > 0:
+            line["viterbi_list_only_rate"] = round(vstats["list_only"] / vstats["wave_steps"], 5)
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)
-        print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            line["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds, args.cpu_turbo_seconds, args.cpu_turbo_cores)
+    finish(line)
 
 
 if __name__ == "__main__":

@@ -194,6 +194,10 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name);
  * parity tests.  name in {"acf" f64[F*lag_stride], "yin" f64[F*yin_stride],
  * "logobs" f64[F*obs_stride], "logunv" f64[F], "states" i32[F], "melpow" f32[F*n_mels]}.
  * Returns the element count available; copies min(count, cap).
+ * "viterbi_stats" i64[2] (reading resets; "viterbi_stats_peek" does not): wave-steps of the band Viterbi since the last
+ * reset and how many of them took the exact observed-sources-only path (bench.py reports the ratio).
+ * "throw_bad_alloc" / "throw_length_error" / "throw_runtime_error" / "throw_int": test hooks of the exception barrier
+ * (the body throws; the call returns AEGIS_ERR_NOMEM / AEGIS_ERR_DEVICE like any other failure).
  * Profiling builds only (csrc/Makefile EXTRA=-DAEGIS_ABLATE=64|128, -DCQT_ABLATE=8; zeros otherwise):
  * "viterbi_cycles" i64[16 waves][8], "frame_cycles" i64[16], "cqt_cycles" i64[16] -- in-kernel s_memtime
  * section counters read by tools/viterbi_cycles.py, frame_cycles.py, cqt_cycles.py (reading resets them). */

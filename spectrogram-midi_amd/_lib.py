@@ -191,6 +191,17 @@ class Handle:
     def kernel_launches(self, name):
         return int(self.lib.aegis_last_kernel_launches(self._h, name.encode()))
 
+    def viterbi_stats(self, reset=True):
+        """{"wave_steps", "list_only"}: voiced-source evaluations of the band Viterbi since the last reset and how many
+        of them took the exact observed-sources-only path (kernels.hip); None on a host-only handle."""
+        if self.device < 0:
+            return None
+        v = np.zeros(2, np.int64)
+        n = int(self.lib.aegis_debug_fetch(self._h, b"viterbi_stats" if reset else b"viterbi_stats_peek", v.ctypes.data, 2))
+        if n < 0:
+            return None
+        return {"wave_steps": int(v[0]), "list_only": int(v[1])}
+
     def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True):
         """clips: list of float32 1-D arrays (host).  Returns a list of per-clip dicts with the
         dtypes of the reference's raw_data (aegis_engine.py:72-75); f0 keeps NaN where unvoiced."""

@@ -57,7 +57,7 @@ struct aegis_handle {
     std::vector<void *> table_allocs;
     // workspace (grow-only)
     DevBuf acf, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
-    DevBuf sample_off, frame_off, order, sel_off, vstate;
+    DevBuf sample_off, frame_off, order, sel_off, vstate, vstats;
     CqtBank cqt_bank;
     DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
@@ -255,6 +255,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     }
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
+    CRT(ensure(h, h->vstats, 16));
+    CRTHIP(hipMemset(h->vstats.p, 0, 16));
     CRTHIP(cqt_configure());
 
     const Tables &t = h->tab;
@@ -311,7 +313,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
     for (DevBuf *b : {&h->acf, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
                       &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
-                      &h->order, &h->sel_off, &h->vstate, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
+                      &h->order, &h->sel_off, &h->vstate, &h->vstats, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb})
         free_buf(*b);
@@ -514,6 +516,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         if (py && (rc = ensure(h, h->vstate, (size_t)nc * S * 8)) != AEGIS_OK) return rc;
         HIPCHK(h, hipMemcpyAsync(h->sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, s));
         p.vstate = static_cast<double *>(h->vstate.p);
+        p.vstats = static_cast<unsigned long long *>(h->vstats.p);
         hipStream_t sv = (nk > 1) ? h->stream2 : s;
         // Large batches are frame-stage bound (every CU carries a Viterbi workgroup): alternating the chunks over two
         // streams lets chunk k+1's FFTs overlap chunk k's latency-bound YIN / observation kernels (256 clips: 273 -> 259 ms).
@@ -1249,6 +1252,19 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     else if (n == "logunv") { src = h->logunv.p; count = F; }
     else if (n == "states") { src = h->states.p; count = F; esz = 4; }
     else if (n == "melpow") { src = h->melpow.p; count = F * h->tab.n_mels; esz = 4; }
+    else if (n == "viterbi_stats" || n == "viterbi_stats_peek") {      // [wave-steps, observed-sources-only wave-steps]
+        if (h->device < 0 || !h->vstats.p) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {
+            long long v[2];
+            std::lock_guard<std::mutex> lock(h->mu);
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, hipMemcpy(v, h->vstats.p, 16, hipMemcpyDeviceToHost));
+            if (n == "viterbi_stats") HIPCHK(h, hipMemset(h->vstats.p, 0, 16));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 2) * 8);
+        }
+        return 2;
+    }
     else if (n == "frame_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;
         if (dst && cap > 0) {

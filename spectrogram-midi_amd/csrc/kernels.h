@@ -62,6 +62,7 @@ struct PassParams {
     double *vstate;              // [n_clips][2*n_bins] column of values at the end of the previous launch
     int32_t *live_states;        // optional [F]: arg-max state of each column as it is produced (streaming preview)
     const StreamCtl *ctl;        // optional: device-resident t_begin / n_sel / vt_begin / vt_end (graph replay)
+    unsigned long long *vstats;  // optional [2]: band Viterbi wave-steps, and how many took the observed-sources-only path
     // workspace (strides in elements)
     double *acf;   int32_t lag_stride;   // [F][lag_stride]   lags 0..max_period
     double *yin;   int32_t yin_stride;   // [F][yin_stride]   CMND for lags min..max

@@ -1074,6 +1074,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int lrlo = max(wlo - H, 0), lrhi = min(whi + H, B - 1);
     const int lw0 = lrlo >> 6, lw1 = lrhi >> 6;
     int cur = 0;
+    int n_list = 0;           // wave-steps that took the observed-sources-only path (wave-uniform)
     for (int t = t_lo; t < t_hi; ++t) {
         VIT_TICK(5)
         double lp = 0.0;
@@ -1179,6 +1180,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         const double MUb = p.log_tiny + (Gp + blt.lmax_all);
         const bool list_only = LT_LDS && __all(!act || (MUb + blt.lmax[0 * 2 + vp] < best1));
 #endif
+        n_list += list_only ? 1 : 0;
         if (list_only) {
             // Second exact prune, per source: an observed voiced source of value vo offers no lane more than
             // vo + lmax; when that is strictly below the smallest unvoiced-chain result of the wave it can neither win
@@ -1306,6 +1308,10 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     }
 #endif
 
+    if (p.vstats != nullptr && lane == 0 && t_hi > t_lo) {
+        atomicAdd(&p.vstats[0], (unsigned long long)(t_hi - t_lo));
+        atomicAdd(&p.vstats[1], (unsigned long long)n_list);
+    }
     if (t_hi < T) {                       // more launches follow: hand the column over
         if (act) vst[j] = myv;
         return;
