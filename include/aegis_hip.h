@@ -191,7 +191,8 @@ int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64
 int64_t aegis_get_param(const aegis_handle *h, const char *name);
 
 /* Copies an intermediate of the most recent pass (device -> host), for stage-level
- * parity tests.  name in {"acf" f64[F*lag_stride], "yin" f64[F*yin_stride],
+ * parity tests.  name in {"dfn" f64[F*lag_stride] (pyin's difference function d[tau], the one pYIN intermediate the
+ * frame stage leaves in HBM), "yin" f64[F*yin_stride] (the CMND rows: only on handles created under AEGIS_DEBUG_STAGES=1),
  * "logobs" f64[F*obs_stride], "logunv" f64[F], "states" i32[F], "melpow" f32[F*n_mels]}.
  * Returns the element count available; copies min(count, cap).
  * "viterbi_stats" i64[2] (reading resets; "viterbi_stats_peek" does not): wave-steps of the band Viterbi since the last
@@ -199,13 +200,13 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name);
  * "throw_bad_alloc" / "throw_length_error" / "throw_runtime_error" / "throw_int": test hooks of the exception barrier
  * (the body throws; the call returns AEGIS_ERR_NOMEM / AEGIS_ERR_DEVICE like any other failure).
  * Profiling builds only (csrc/Makefile EXTRA=-DAEGIS_ABLATE=64|128, -DCQT_ABLATE=8; zeros otherwise):
- * "viterbi_cycles" i64[16 waves][8], "frame_cycles" i64[16], "cqt_cycles" i64[16] -- in-kernel s_memtime
- * section counters read by tools/viterbi_cycles.py, frame_cycles.py, cqt_cycles.py (reading resets them). */
+ * "viterbi_cycles" i64[16 waves][8], "cqt_cycles" i64[16] -- in-kernel s_memtime
+ * section counters read by tools/viterbi_cycles.py, cqt_cycles.py (reading resets them). */
 int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t cap);
 
 /* Kernel timing of the most recent aegis_analyze_batch_device() with sync != 0,
  * measured with hipEvents on the stream the kernels ran on.  name in
- * {"frame_fft","yin_seq","pyin_obs","viterbi","finalize","total"}; milliseconds,
+ * {"frame","pyin_obs","viterbi","finalize","total"}; milliseconds,
  * negative when unavailable.  aegis_set_profiling(h, 1) enables the events. */
 int aegis_set_profiling(aegis_handle *h, int32_t on);
 double aegis_last_kernel_ms(const aegis_handle *h, const char *name);

@@ -47,6 +47,7 @@ struct aegis_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
+    bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
@@ -56,7 +57,7 @@ struct aegis_handle {
     mutable std::string err;
     std::vector<void *> table_allocs;
     // workspace (grow-only)
-    DevBuf acf, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
+    DevBuf dfn, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
     DevBuf sample_off, frame_off, order, sel_off, vstate, vstats;
     CqtBank cqt_bank;
     DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
@@ -88,7 +89,7 @@ struct aegis_stream {
     int64_t n_samples = 0;      // samples received
     int64_t frames_done = 0;    // frames analysed (= Viterbi columns produced)
     bool closed = false;
-    DevBuf pcm, acf, yin, logobs, logunv, ptr, cmap, bnd, states, live, melpow, clipmax, rake_raw, vstate, meta;
+    DevBuf pcm, dfn, logobs, logunv, ptr, cmap, bnd, states, live, melpow, clipmax, rake_raw, vstate, meta;
     DevBuf o_f0, o_voiced, o_vprob, o_rms, o_rake, o_sdb;
     std::vector<int64_t> host_meta;
     // captured hipGraph of one fixed-size push (built lazily for the first push size that is a multiple of hop)
@@ -253,6 +254,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
         const long v = std::strtol(e, nullptr, 10);
         if (v >= 64 && v % kViterbiChunk == 0) h->time_chunk = v;
     }
+    if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
     CRT(ensure(h, h->vstats, 16));
@@ -311,7 +313,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
-    for (DevBuf *b : {&h->acf, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
+    for (DevBuf *b : {&h->dfn, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
                       &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
                       &h->order, &h->sel_off, &h->vstate, &h->vstats, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
@@ -436,7 +438,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
 #define ENS(buf, bytes) if ((rc = ensure(h, h->buf, (size_t)(bytes))) != AEGIS_OK) return rc
         ENS(sample_off, (nc + 1) * 8); ENS(frame_off, (nc + 1) * 8); ENS(order, nc * 4); ENS(chunk_off, (nc + 1) * 8);
         if (stages & AEGIS_STAGE_PYIN) {
-            ENS(acf, fp * h->lag_stride * 8); ENS(yin, fp * h->yin_stride * 8);
+            ENS(dfn, fp * h->lag_stride * 8); if (h->debug_stages) ENS(yin, fp * h->yin_stride * 8);
             ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8);
             ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
             ENS(states, fp * 4);
@@ -456,8 +458,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.frame_off = static_cast<const int64_t *>(h->frame_off.p);
         p.order = static_cast<const int32_t *>(h->order.p);
         p.n_clips = nc; p.n_frames = fp;
-        p.acf = static_cast<double *>(h->acf.p); p.lag_stride = h->lag_stride;
-        p.yin = static_cast<double *>(h->yin.p); p.yin_stride = h->yin_stride;
+        p.dfn = static_cast<double *>(h->dfn.p); p.lag_stride = h->lag_stride;
+        p.yin = ((stages & AEGIS_STAGE_PYIN) && h->debug_stages) ? static_cast<double *>(h->yin.p) : nullptr; p.yin_stride = h->yin_stride;
         p.logobs = static_cast<double *>(h->logobs.p); p.obs_stride = h->obs_stride;
         p.logunv = static_cast<double *>(h->logunv.p);
         p.ptr = static_cast<uint16_t *>(h->ptr.p);
@@ -560,9 +562,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     HIPCHK(h, hipStreamWaitEvent(fs, h->copy_event, 0));
                 }
             }
-            begin_event(h, "frame_fft", fs); launch_frame_fft(p, h->dt, fs); end_event(h, fs);
+            begin_event(h, "frame", fs); launch_frame(p, h->dt, fs); end_event(h, fs);
             if (py) {
-                begin_event(h, "yin_seq", fs); launch_yin_seq(p, h->dt, fs); end_event(h, fs);
                 begin_event(h, "pyin_obs", fs); launch_pyin_obs(p, h->dt, fs); end_event(h, fs);
                 if (nk > 1) {
                     HIPCHK(h, hipEventRecord(h->sync_events[k], fs));
@@ -739,8 +740,8 @@ static PassParams stream_params(aegis_stream *st, const int64_t *dm) {
     p.chunk_off = const_cast<int64_t *>(dm + 6);
     p.order = reinterpret_cast<const int32_t *>(dm + 8);
     p.n_clips = 1;
-    p.acf = static_cast<double *>(st->acf.p); p.lag_stride = h->lag_stride;
-    p.yin = static_cast<double *>(st->yin.p); p.yin_stride = h->yin_stride;
+    p.dfn = static_cast<double *>(st->dfn.p); p.lag_stride = h->lag_stride;
+    p.yin = nullptr; p.yin_stride = h->yin_stride;
     p.logobs = static_cast<double *>(st->logobs.p); p.obs_stride = h->obs_stride;
     p.logunv = static_cast<double *>(st->logunv.p);
     p.ptr = static_cast<uint16_t *>(st->ptr.p); p.cmap = static_cast<uint16_t *>(st->cmap.p);
@@ -774,8 +775,7 @@ static bool stream_build_graph(aegis_stream *st, int64_t n_push, hipStream_t s) 
     bool ok = true;
     ok &= hipMemcpyAsync(st->g_staging.p, st->pin_samples, n_push * 4, hipMemcpyHostToDevice, s) == hipSuccess;
     launch_stream_advance(ctl, static_cast<const float *>(st->g_staging.p), (int)n_push, static_cast<float *>(st->pcm.p), t.hop, s);
-    launch_frame_fft(p, h->dt, s);
-    launch_yin_seq(p, h->dt, s);
+    launch_frame(p, h->dt, s);
     launch_pyin_obs(p, h->dt, s);
     ok &= launch_viterbi(p, h->dt, t.log_trans_band.data(), s) == hipSuccess;
     launch_stream_gather(ctl, p.out_rms, p.out_vprob, p.live_states, st->g_result.p, s);
@@ -810,8 +810,7 @@ static int stream_run(aegis_stream *st, int64_t f_lo, int64_t f_hi, bool final_p
     p.vt_begin = f_lo; p.vt_end = final_pass ? INT64_MAX : f_hi;
     (void)S;
     if (p.n_sel > 0) {
-        launch_frame_fft(p, h->dt, s);
-        launch_yin_seq(p, h->dt, s);
+        launch_frame(p, h->dt, s);
         launch_pyin_obs(p, h->dt, s);
     }
     if (p.n_sel > 0 || final_pass) {
@@ -829,7 +828,7 @@ static void stream_release(aegis_stream *st) noexcept {
     if (st->graph) (void)hipGraphDestroy(st->graph);
     if (st->pin_samples) (void)hipHostFree(st->pin_samples);
     if (st->pin_result) (void)hipHostFree(st->pin_result);
-    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->acf, &st->yin, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
+    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->dfn, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
                       &st->live, &st->melpow, &st->clipmax, &st->rake_raw, &st->vstate, &st->meta, &st->o_f0, &st->o_voiced,
                       &st->o_vprob, &st->o_rms, &st->o_rake, &st->o_sdb})
         free_buf(*b);
@@ -846,7 +845,7 @@ static int stream_open_locked(aegis_handle *h, int64_t max_samples, aegis_stream
     const int64_t nch = (F - 1 + kViterbiChunk - 1) / kViterbiChunk + 1;
     int rc = AEGIS_OK;
     auto need = [&](DevBuf &b, size_t bytes) { if (rc == AEGIS_OK) rc = ensure(h, b, bytes); };
-    need(st->pcm, max_samples * 4); need(st->acf, F * h->lag_stride * 8); need(st->yin, F * h->yin_stride * 8);
+    need(st->pcm, max_samples * 4); need(st->dfn, F * h->lag_stride * 8);
     need(st->logobs, F * h->obs_stride * 8); need(st->logunv, F * 8); need(st->ptr, F * S * 2);
     need(st->cmap, nch * S * 2); need(st->bnd, nch * 4); need(st->states, F * 4); need(st->live, F * 4);
     need(st->melpow, F * t.n_mels * 4); need(st->clipmax, 16); need(st->rake_raw, F); need(st->vstate, S * 8);
@@ -1246,7 +1245,7 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     const void *src = nullptr;
     int64_t count = 0;
     size_t esz = 8;
-    if (n == "acf") { src = h->acf.p; count = F * h->lag_stride; }
+    if (n == "dfn") { src = h->dfn.p; count = F * h->lag_stride; }
     else if (n == "yin") { src = h->yin.p; count = F * h->yin_stride; }
     else if (n == "logobs") { src = h->logobs.p; count = F * h->obs_stride; }
     else if (n == "logunv") { src = h->logunv.p; count = F; }
@@ -1264,17 +1263,6 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
             std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 2) * 8);
         }
         return 2;
-    }
-    else if (n == "frame_cycles") {
-        if (h->device < 0) return AEGIS_ERR_INVALID;
-        if (dst && cap > 0) {
-            long long v[16];
-            HIPCHK(h, hipSetDevice(h->device));
-            HIPCHK(h, hipDeviceSynchronize());
-            HIPCHK(h, frame_debug_fetch(v));
-            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
-        }
-        return 16;
     }
     else if (n == "viterbi_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;

@@ -64,8 +64,8 @@ struct PassParams {
     const StreamCtl *ctl;        // optional: device-resident t_begin / n_sel / vt_begin / vt_end (graph replay)
     unsigned long long *vstats;  // optional [2]: band Viterbi wave-steps, and how many took the observed-sources-only path
     // workspace (strides in elements)
-    double *acf;   int32_t lag_stride;   // [F][lag_stride]   lags 0..max_period
-    double *yin;   int32_t yin_stride;   // [F][yin_stride]   CMND for lags min..max
+    double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period
+    double *yin;   int32_t yin_stride;   // optional [F][yin_stride]: CMND for lags min..max, written only for the stage tests
     double *logobs; int32_t obs_stride;  // [F][obs_stride]   log(obs+tiny), voiced bins
     double *logunv;                      // [F]               log(unvoiced obs+tiny)
     uint16_t *ptr;                       // [F][2*n_bins]     Viterbi back-pointers
@@ -85,8 +85,7 @@ struct PassParams {
 
 constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
 
-void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s);
-void launch_yin_seq(const PassParams &p, const DevTables &t, hipStream_t s);
+void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);
@@ -96,7 +95,6 @@ void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, 
 void launch_stream_advance(StreamCtl *ctl, const float *staging, int n_push, float *pcm, int hop, hipStream_t s);
 void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *vprob, const int32_t *live, void *result,
                           hipStream_t s);
-hipError_t frame_debug_fetch(long long *dst);                // frame_fft_kernel section cycles (AEGIS_ABLATE&128)
 hipError_t viterbi_debug_fetch(long long *dst, bool reset);   // per-wave section cycles (zeros unless AEGIS_ABLATE&64)
 hipError_t viterbi_configure();   // raises the dynamic-LDS limit once
 

@@ -12,6 +12,7 @@
 // Built with -ffp-contract=off: every multiply/add below rounds exactly where
 // NumPy rounds; fused operations are written as fma() where they are wanted.
 #include "kernels.h"
+#include "fft8.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -45,297 +46,29 @@ __device__ __forceinline__ void map_frame(const PassParams &p, int64_t fs, int &
     f = p.frame_off[c] + t;
 }
 
-__device__ __forceinline__ double2 cmul(double2 a, double2 b) {
-    return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
-}
-__device__ __forceinline__ double2 cadd(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ double2 csub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 
 // ------------------------------------------------------------------------------------------
-// 2048-point complex FFT, float64, Stockham autosort in LDS: five radix-4 passes and one
-// radix-2 pass by NT cooperating threads.  Forward transform (e^{-2 pi i jk/N}); input and
-// result in `a`, `b` is the second buffer.  Callers synchronise before the call; every pass
-// ends with a workgroup barrier, so all threads of the workgroup must make the same calls.
+// Kernel 1: frame stage.  A 256-thread workgroup owns `frames_per_wg` consecutive selected frames (16 in batch
+// launches, 2 for streaming pushes) and takes them two at a time; 81 KB of LDS, so two workgroups share a CU.
+//
+//   prologue  float32 running energy of pyin's difference function for ALL the workgroup's frames at once, one frame
+//             per lane of wave 0: e = np.cumsum(frame**2) is strictly sequential, so the lanes walk their own frame
+//             (samples straight from global memory, 16-byte loads, next block in flight) and leave
+//             en[tau] = e[1024 + tau] - e[tau] in an LDS row per frame.  Same operations in the same order as NumPy.
+//   per frame centred frame -> LDS (zero padded at the clip edges; the next frame's samples are already in flight),
+//             feature.rms in NumPy's float32 pairwise order (bit-exact), ONE packed forward FFT
+//             Z = FFT(x + i*b), b = reversed first half: A = FFT(x) and B = FFT(b) separate by symmetry, P = A*B is the
+//             spectrum of pyin's autocorrelation, and the Hann-windowed spectrum librosa.stft needs is
+//             XW[k] = A[k]/2 - (A[k-1] + A[k+1])/4 (periodic Hann in the frequency domain): the mel path costs no FFT.
+//             |XW|^2 rounded through complex64 like librosa.stft -> sparse Slaney mel -> clip maximum.
+//   per pair  ONE inverse FFT for both frames (Q = P0 + i*P1 by Hermitian extension) -> acf0 + i*acf1, then
+//             d[tau] = (en[0] + en[tau]) - 2 acf[tau] with librosa's |.| < 1e-6 clamps, written to HBM (the only
+//             pYIN intermediate this kernel materialises; the CMND cumsum and quotient open pyin_obs_kernel).
+// FFT: csrc/fft8.h (radix 8 x 8 x 8 x 4 in registers, one in-place LDS buffer).  1.5 FFTs per frame.
 // ------------------------------------------------------------------------------------------
-// The twiddles a thread needs do not depend on the data: in the radix-4 pass of stride NS thread j uses
-// tw[m], tw[2m], tw[3m] with m = (j & (NS-1)) * 512/NS, and j & (NS-1) only depends on j mod 256 for NS <= 256,
-// so the two butterflies of a 256-thread FFT and the one of the 512-thread FFT share them; the last radix-2
-// pass multiplies element j + 1024 by tw[j], j = lt + 256*q.  They are read from the table ONCE per workgroup
-// into registers (16 double2) instead of 3 global loads per butterfly and pass.
-struct FftTw {
-    double2 r4[4][3];   // passes NS = 4, 16, 64, 256
-    double2 last[4];    // tw[lt + 256*q]
-};
-__device__ __forceinline__ void load_fft_twiddles(FftTw &w, const double2 *__restrict__ tw, int lt) {
-#pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-        const int NS = 4 << (2 * ps);
-        const int m = (lt & (NS - 1)) * (2048 / (NS * 4));
-        w.r4[ps][0] = tw[m]; w.r4[ps][1] = tw[2 * m]; w.r4[ps][2] = tw[3 * m];
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) w.last[q] = tw[lt + 256 * q];
-}
+constexpr int kFramesPerWg = 16;
 
-template <int NS, int NT>
-__device__ __forceinline__ void fft_pass_r4(const double2 *__restrict__ in, double2 *__restrict__ out,
-                                            const double2 (&w3)[3], int tid) {
-#pragma unroll
-    for (int jj = 0; jj < 512 / NT; ++jj) {
-        const int j = tid + jj * NT;
-        const int k = j & (NS - 1);
-        double2 v0 = in[j], v1 = in[j + 512], v2 = in[j + 1024], v3 = in[j + 1536];
-        if (NS > 1) {
-            v1 = cmul(v1, w3[0]);
-            v2 = cmul(v2, w3[1]);
-            v3 = cmul(v3, w3[2]);
-        }
-        const double2 a0 = cadd(v0, v2), a1 = csub(v0, v2), a2 = cadd(v1, v3);
-        double2 a3 = csub(v1, v3);
-        a3 = make_double2(a3.y, -a3.x);   // * (-i)
-        const int j0 = ((j - k) << 2) + k;
-        out[j0] = cadd(a0, a2);
-        out[j0 + NS] = cadd(a1, a3);
-        out[j0 + 2 * NS] = csub(a0, a2);
-        out[j0 + 3 * NS] = csub(a1, a3);
-    }
-}
-
-// hh = tid / 256 (0 for the 256-thread transforms)
-template <int NT>
-__device__ __forceinline__ void fft_pass_r2_last(const double2 *__restrict__ in, double2 *__restrict__ out,
-                                                 const FftTw &w, int tid, int hh) {
-#pragma unroll
-    for (int jj = 0; jj < 1024 / NT; ++jj) {
-        const int j = tid + jj * NT;   // 0..1023, Ns = 1024 -> k = j, j0 = j
-        const double2 t = NT == 256 ? w.last[jj] : (hh ? w.last[1 + 2 * jj] : w.last[2 * jj]);
-        const double2 v0 = in[j];
-        const double2 v1 = cmul(in[j + 1024], t);
-        out[j] = cadd(v0, v1);
-        out[j + 1024] = csub(v0, v1);
-    }
-}
-
-template <int NT>
-__device__ __forceinline__ void fft2048(double2 *a, double2 *b, const FftTw &w, int tid, int hh) {
-    fft_pass_r4<1, NT>(a, b, w.r4[0], tid);   __syncthreads();
-    fft_pass_r4<4, NT>(b, a, w.r4[0], tid);   __syncthreads();
-    fft_pass_r4<16, NT>(a, b, w.r4[1], tid);  __syncthreads();
-    fft_pass_r4<64, NT>(b, a, w.r4[2], tid);  __syncthreads();
-    fft_pass_r4<256, NT>(a, b, w.r4[3], tid); __syncthreads();
-    fft_pass_r2_last<NT>(b, a, w, tid, hh);   __syncthreads();
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 1: two frames per 512-thread workgroup (one per 256-thread half).
-//   * loads the centred frames (zero padded at the clip edges) with coalesced reads
-//   * RMS in NumPy's float32 pairwise-summation order (bit-exact with np.mean)
-//   * one packed forward FFT per frame: Z = FFT(x + i*b), b = reversed first half of the frame.
-//       A = FFT(x), B = FFT(b) are separated from Z by symmetry;
-//       P = A*B is the spectrum of pyin's autocorrelation;
-//       the Hann-windowed spectrum librosa.stft needs is XW[k] = A[k]/2 - (A[k-1] + A[k+1])/4
-//       (periodic Hann = 1/2 - 1/4 e^{+i..} - 1/4 e^{-i..}), so the mel path costs no FFT.
-//   * ONE inverse FFT for both frames: Q = P0 + i*P1 (Hermitian extensions) -> acf0 + i*acf1
-//   * |XW|^2 rounded through complex64 like librosa.stft -> Slaney mel -> clip max
-// 1.5 FFTs per frame instead of 3.
-// ------------------------------------------------------------------------------------------
-constexpr int kFramePairs = 8;   // frame pairs per workgroup of frame_fft_kernel (1 for small launches: streaming pushes)
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-__device__ long long g_frm_dbg[16];
-#define FRM_TICK(k) { const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
-#else
-#define FRM_TICK(k)
-#endif
-__global__ __launch_bounds__(512) void frame_fft_kernel(PassParams p, DevTables tb, int pairs_per_wg) {
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-    long long facc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, flast = clock64();
-#endif
-    extern __shared__ __align__(16) unsigned char fsm[];
-    double2 *bufs = reinterpret_cast<double2 *>(fsm);            // [2 halves][2][2048]
-    float *xs_all = reinterpret_cast<float *>(bufs + 4 * 2048);  // [2][2048]
-    float *pw_all = xs_all + 2 * 2048;                           // [2][1032]
-    float *red_all = pw_all + 2 * 1032;                          // [2][128]
-    float *blk_all = red_all + 2 * 128;                          // [2][16]
-    unsigned *smax_all = reinterpret_cast<unsigned *>(blk_all + 2 * 16);   // [2]
-
-    const int tid = threadIdx.x, hh = tid >> 8, lt = tid & 255;
-    double2 *bufA = bufs + hh * 4096, *bufB = bufA + 2048;
-    float *xs = xs_all + hh * 2048, *pw = pw_all + hh * 1032, *red = red_all + hh * 128, *blk = blk_all + hh * 16;
-
-    // One workgroup owns kFramePairs consecutive frame pairs (it has the CU to itself: 153 KB of LDS).  The
-    // samples of the next pair are fetched into registers while the current pair is transformed, and the FFT
-    // twiddles are read once; both used to be exposed global-memory latency in every pair.
-    struct Geo { bool live; int c; int64_t base, n, start, f; };
-    auto locate = [&](int it) {
-        Geo g{false, 0, 0, 0, 0, 0};
-        const int64_t fs = ((int64_t)blockIdx.x * pairs_per_wg + it) * 2 + hh;
-        g.live = it < pairs_per_wg && fs < geo_n_sel(p);
-        if (g.live) {
-            int64_t t;
-            map_frame(p, fs, g.c, t, g.f);
-            g.base = p.sample_off[g.c];
-            g.n = p.sample_off[g.c + 1] - g.base;
-            g.start = t * p.hop - 1024;
-        }
-        return g;
-    };
-    auto fetch = [&](const Geo &g, float (&v)[8]) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const int64_t idx = g.start + lt + r * 256;
-            v[r] = (g.live && idx >= 0 && idx < g.n) ? p.pcm[g.base + idx] : 0.0f;
-        }
-    };
-    Geo geo = locate(0);
-    float nx[8];
-    fetch(geo, nx);
-    FftTw twr;
-    load_fft_twiddles(twr, tb.twiddle, lt);
-
-    for (int it = 0; it < pairs_per_wg; ++it) {
-    const bool live = geo.live;
-    const int c = geo.c;
-    const int64_t f = geo.f;
-    if (it > 0) __syncthreads();          // the previous pair's inverse transform still reads the buffers
-#pragma unroll
-    for (int r = 0; r < 8; ++r) xs[lt + r * 256] = nx[r];
-    if (lt == 0) smax_all[hh] = 0u;
-    geo = locate(it + 1);
-    fetch(geo, nx);                       // in flight under everything below
-    __syncthreads();
-    FRM_TICK(0)
-
-    // ---- feature.rms: np.mean(np.square(x), axis=-2) then sqrt, float32 ----------------------
-    const bool want_rms = (p.stages & 0x8u) && p.out_rms != nullptr;
-    if (want_rms) {
-        if (lt < 128) {
-            const int bb = lt >> 3, a = lt & 7;
-            const float *xb = xs + bb * 128 + a;
-            float r = xb[0] * xb[0];
-#pragma unroll
-            for (int i = 1; i < 16; ++i) { const float v = xb[8 * i]; r = r + v * v; }
-            red[lt] = r;
-        }
-        __syncthreads();
-        if (lt < 16) {
-            const float *r = red + lt * 8;
-            blk[lt] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        }
-        __syncthreads();
-        if (lt == 0 && live) {
-            float b0 = (blk[0] + blk[1]) + (blk[2] + blk[3]);
-            float b1 = (blk[4] + blk[5]) + (blk[6] + blk[7]);
-            float b2 = (blk[8] + blk[9]) + (blk[10] + blk[11]);
-            float b3 = (blk[12] + blk[13]) + (blk[14] + blk[15]);
-            const float total = 0.0f + ((b0 + b1) + (b2 + b3));
-            p.out_rms[f] = sqrtf(total / 2048.0f);
-        }
-    }
-    if (!(p.stages & 0x7u)) continue;
-    FRM_TICK(1)
-
-    // ---- packed forward FFT of (frame, reversed first half) ---------------------------------
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int i = lt + r * 256;
-        bufA[i] = make_double2((double)xs[i], i < 1024 ? (double)xs[1024 - i] : 0.0);
-    }
-    __syncthreads();
-    fft2048<256>(bufA, bufB, twr, lt, 0);
-    FRM_TICK(2)
-
-    // A[k] -> bufB[k] (k <= 1024); P[k] = A[k]*B[k] kept in registers
-    double2 P[5];
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int k = lt + r * 256;
-        P[r] = make_double2(0.0, 0.0);
-        if (k <= 1024) {
-            const double2 zk = bufA[k], zn = bufA[(2048 - k) & 2047];
-            const double2 A = make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
-            const double2 Bv = make_double2((zk.y + zn.y) * 0.5, (zn.x - zk.x) * 0.5);
-            P[r] = cmul(A, Bv);
-            bufB[k] = A;
-        }
-    }
-    __syncthreads();
-    // windowed power spectrum from A (bufB); P -> bufA[k]
-#pragma unroll
-    for (int r = 0; r < 5; ++r) {
-        const int k = lt + r * 256;
-        if (k <= 1024) {
-            if (p.stages & 0x3u) {
-                const double2 a0 = bufB[k];
-                double2 am = bufB[k == 0 ? 1 : k - 1], ap = bufB[k == 1024 ? 1023 : k + 1];
-                if (k == 0) am.y = -am.y;          // A[-1] = conj(A[1])
-                if (k == 1024) ap.y = -ap.y;       // A[1025] = conj(A[1023])
-                const float re = (float)(0.5 * a0.x - 0.25 * (am.x + ap.x));
-                const float im = (float)(0.5 * a0.y - 0.25 * (am.y + ap.y));
-                const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
-                pw[k] = mag * mag;
-            }
-            bufA[k] = P[r];
-        }
-    }
-    __syncthreads();
-
-    FRM_TICK(3)
-    // ---- mel projection (each half: its own frame) -------------------------------------------
-    if (p.stages & 0x3u) {
-        if (lt < p.n_mels && live) {
-            const int s0 = tb.mel_start[lt], len = tb.mel_len[lt];
-            const float *w = tb.mel_w + tb.mel_off[lt];
-            float acc = 0.0f;
-            for (int i = 0; i < len; ++i) acc = fmaf(w[i], pw[s0 + i], acc);
-            p.melpow[f * p.n_mels + lt] = acc;
-            atomicMax(&smax_all[hh], __float_as_uint(acc));
-        }
-    }
-    FRM_TICK(4)
-    // ---- one inverse FFT for both frames -------------------------------------------------------
-    if (p.stages & 0x4u) {
-        // conj(Q), Q = Hermitian extension of P0 + i*P1, built by all 512 threads into bufs[0].B
-        double2 *q = bufs + 2048, *q2 = bufs + 3 * 2048;
-        const double2 *P0 = bufs, *P1 = bufs + 4096;
-        for (int k = tid; k <= 1024; k += 512) {
-            const double2 u = P0[k], v = P1[k];
-            q[k] = make_double2(u.x - v.y, -u.y - v.x);                       // conj(P0) - i conj(P1)
-            if (k > 0 && k < 1024) q[2048 - k] = make_double2(u.x + v.y, u.y - v.x);   // P0 - i P1
-        }
-        __syncthreads();
-        fft2048<512>(q, q2, twr, tid, hh);
-        FRM_TICK(5)
-        // FFT(conj Q) = N * conj(acf0 + i acf1)
-        if (live) {
-            double *acf = p.acf + f * (int64_t)p.lag_stride;
-            for (int tau = lt; tau <= p.max_period; tau += 256) {
-                const double2 z = q[1024 + tau];
-                acf[tau] = (hh == 0 ? z.x : -z.y) * (1.0 / 2048.0);
-            }
-        }
-    } else {
-        __syncthreads();
-    }
-    if ((p.stages & 0x3u) && lt == 0 && live) atomicMax(&p.clipmax[c], smax_all[hh]);
-    FRM_TICK(6)
-    }   // frame pairs
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-    if (blockIdx.x == 1000 && tid == 0) { for (int k = 0; k < 7; ++k) g_frm_dbg[k] = facc[k]; }
-#endif
-}
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-hipError_t frame_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_frm_dbg), sizeof(long long) * 16); }
-#else
-hipError_t frame_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
-#endif
-
-// ------------------------------------------------------------------------------------------
-// Kernel 2: one frame per lane.  Everything here is sequential along the lag axis in the
-// reference (np.cumsum in float32 for the energy, in float64 for the CMND denominator), so
-// the lanes walk their own frame serially and stay bit-exact with NumPy.
-// ------------------------------------------------------------------------------------------
-// 8 consecutive samples x[idx..idx+7] with zero fill outside [0, n); one 128-byte line per lane
-// is consumed by four such calls, so the wave's loads of a line stay adjacent in time.
+// 8 consecutive samples x[idx..idx+7] with zero fill outside [0, n)
 __device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, int64_t idx, bool vec_ok, float (&v)[8]) {
     if (vec_ok && idx >= 0 && idx + 7 < n) {
         const float4 a = *reinterpret_cast<const float4 *>(x + idx);
@@ -347,120 +80,265 @@ __device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, in
     }
 }
 
-__global__ __launch_bounds__(64) void yin_seq_kernel(PassParams p) {
-    const int64_t fs = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (fs >= geo_n_sel(p)) return;
-    int c;
-    int64_t t, f;
-    map_frame(p, fs, c, t, f);
-    const int64_t base = p.sample_off[c];
-    const int64_t n = p.sample_off[c + 1] - base;
-    const int64_t start = t * p.hop - 1024;
-    const float *__restrict__ x = p.pcm + base;
-    // float4 loads need 16-byte aligned addresses: clip base and hop multiples of 4 samples
-    const bool vec_ok = ((base & 3) == 0) && ((p.hop & 3) == 0);
-
-    // e_hi = cumsum(x^2)[k] for k < 1024 (float32, strictly sequential like np.cumsum)
-    float e_hi = 0.0f;
-    float v[8], w[8];
-    for (int k = 0; k < 1024; k += 8) {
-        load8(x, n, start + k, vec_ok, v);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float sq = v[i] * v[i];
-            e_hi = (k + i == 0) ? sq : e_hi + sq;
-        }
-    }
-    const double *__restrict__ acf = p.acf + f * (int64_t)p.lag_stride;
-    double *__restrict__ yin = p.yin + f * (int64_t)p.yin_stride;
-    float e_lo = 0.0f, en0 = 0.0f;
-    double cs = 0.0;
-    for (int tau0 = 0; tau0 <= p.max_period; tau0 += 8) {
-        load8(x, n, start + 1024 + tau0, vec_ok, v);
-        load8(x, n, start + tau0, vec_ok, w);
-        double a8[8];
-        if (tau0 + 7 < p.lag_stride) {     // rows are padded to a multiple of 8 lags
-#pragma unroll
-            for (int i = 0; i < 8; i += 2) {
-                const double2 a2 = *reinterpret_cast<const double2 *>(acf + tau0 + i);
-                a8[i] = a2.x; a8[i + 1] = a2.y;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) a8[i] = tau0 + i <= p.max_period ? acf[tau0 + i] : 0.0;
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int tau = tau0 + i;
-            if (tau > p.max_period) break;
-            e_hi = e_hi + v[i] * v[i];
-            const float sq = w[i] * w[i];
-            e_lo = (tau == 0) ? sq : e_lo + sq;
-            float en = e_hi - e_lo;
-            if (fabsf(en) < 1e-6f) en = 0.0f;
-            if (tau == 0) en0 = en;
-            double a = a8[i];
-            if (fabs(a) < 1e-6) a = 0.0;
-            const float esum = en0 + en;
-            const double d = (double)esum - 2.0 * a;
-            if (tau >= 1) cs = (tau == 1) ? d : cs + d;
-            if (tau >= p.min_period) yin[tau - p.min_period] = d / (cs / (double)tau + DBL_MIN);
-        }
-    }
+// floats per running-energy row: lags 0..max_period, a multiple of 4 whose quarter is odd, so that the 16-byte
+// accesses of 16 lanes (one row each) fall on 16 distinct bank groups
+__host__ __device__ inline int frame_en_stride(int max_period) {
+    int s = (max_period + 1 + 3) & ~3;
+    if (((s >> 2) & 1) == 0) s += 4;
+    return s;
 }
+constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1032 * 4 + 128 * 4 + 16 * 4;
 
-// Latency variant of kernel 2 for small selections (streaming pushes): one frame per 128-thread
-// workgroup.  The frame is staged in LDS; the two float32 running sums (cumsum up to 1024+tau, cumsum up
-// to tau) are walked by lane 0 of wave 0 and of wave 1 concurrently, the difference function is formed in
-// parallel, only the float64 cumsum of d stays serial, and the CMND quotient is parallel again.  Same
-// operations in the same order as yin_seq_kernel: bit-identical output.
-__global__ __launch_bounds__(128) void yin_seq_wave_kernel(PassParams p) {
-    __shared__ float xs[2048];
-    __shared__ float ehi[1024], elo[1024];
-    __shared__ double dd[1024], cs[1024];
-    const int tid = threadIdx.x;
-    if ((int64_t)blockIdx.x >= geo_n_sel(p)) return;
-    int c;
-    int64_t t, f;
-    map_frame(p, (int64_t)blockIdx.x, c, t, f);
-    const int64_t base = p.sample_off[c];
-    const int64_t n = p.sample_off[c + 1] - base;
-    const int64_t start = t * p.hop - 1024;
-    for (int i = tid; i < 2048; i += 128) {
-        const int64_t idx = start + i;
-        xs[i] = (idx >= 0 && idx < n) ? p.pcm[base + idx] : 0.0f;
-    }
-    __syncthreads();
+__global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTables tb, int frames_per_wg, int en_stride) {
+    extern __shared__ __align__(16) unsigned char fsm[];
+    double2 *z = reinterpret_cast<double2 *>(fsm);               // [2048] FFT buffer (swizzled index, fft8.h)
+    float *xs = reinterpret_cast<float *>(z + 2048);             // [2048] the frame
+    float *pw = xs + 2048;                                       // [1032] windowed power spectrum
+    float *red = pw + 1032;                                      // [128]  rms partial sums
+    float *blk = red + 128;                                      // [16]
+    float *en = blk + 16;                                        // [frames_per_wg][en_stride] running energies
+
+    const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    const int64_t n_sel = geo_n_sel(p);
+    const int64_t fs0 = (int64_t)blockIdx.x * frames_per_wg;
+    if (fs0 >= n_sel) return;
+    const int nfr = (int)min((int64_t)frames_per_wg, n_sel - fs0);
+    const bool want_pyin = (p.stages & 0x4u) != 0, want_mel = (p.stages & 0x3u) != 0;
+    const bool want_rms = (p.stages & 0x8u) && p.out_rms != nullptr;
+    const bool want_fft = (p.stages & 0x7u) != 0;
     const int mp = p.max_period;
-    if (tid == 0) {
+
+    struct Geo { bool live; int c; int64_t base, n, start, f; };
+    auto locate = [&](int i) {
+        Geo g{false, 0, 0, 0, 0, 0};
+        g.live = i < nfr;
+        if (g.live) {
+            int64_t t;
+            map_frame(p, fs0 + i, g.c, t, g.f);
+            g.base = p.sample_off[g.c];
+            g.n = p.sample_off[g.c + 1] - g.base;
+            g.start = t * p.hop - 1024;
+        }
+        return g;
+    };
+    auto fetch = [&](const Geo &g, float (&v)[8]) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int64_t idx = g.start + tid + r * 256;
+            v[r] = (g.live && idx >= 0 && idx < g.n) ? p.pcm[g.base + idx] : 0.0f;
+        }
+    };
+    Geo geo = locate(0);
+    float nx[8];
+    fetch(geo, nx);
+    Fft8Tw twr;
+    if (want_fft) fft8_load_twiddles(twr, tb.twiddle, tid);
+
+    // ---- prologue: running energy of every frame of the workgroup, one frame per lane ------------------------
+    if (want_pyin && wid == 0 && lane < nfr) {
+        const Geo g = locate(lane);
+        const float *__restrict__ x = p.pcm + g.base;
+        // float4 loads need 16-byte aligned addresses: clip base and hop multiples of 4 samples
+        const bool vec_ok = ((g.base & 3) == 0) && ((p.hop & 3) == 0);
+        float *row = en + lane * en_stride;
+        float v[8], nv[8];
+        load8(x, g.n, g.start, vec_ok, v);
         float e = 0.0f;
-        for (int k = 0; k < 1024; ++k) { const float sq = xs[k] * xs[k]; e = (k == 0) ? sq : e + sq; }
-        for (int tau = 0; tau <= mp; ++tau) { const float v = xs[1024 + tau]; e = e + v * v; ehi[tau] = e; }
-    } else if (tid == 64) {
-        float e = 0.0f;
-        for (int tau = 0; tau <= mp; ++tau) { const float sq = xs[tau] * xs[tau]; e = (tau == 0) ? sq : e + sq; elo[tau] = e; }
+        const int jend = 1024 + mp + 1;              // e[j] is needed for j <= 1024 + max_period
+        for (int j0 = 0; j0 < jend; j0 += 8) {
+            if (j0 + 8 < jend) load8(x, g.n, g.start + j0 + 8, vec_ok, nv);
+            float ev[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float sq = v[i] * v[i];
+                e = (j0 + i == 0) ? sq : e + sq;     // np.cumsum: strictly sequential float32 adds
+                ev[i] = e;
+            }
+            if (j0 + 7 <= mp) {                      // e[tau], tau <= max_period: kept for the subtraction below
+                *reinterpret_cast<float4 *>(row + j0) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+                *reinterpret_cast<float4 *>(row + j0 + 4) = make_float4(ev[4], ev[5], ev[6], ev[7]);
+            } else if (j0 <= mp) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) if (j0 + i <= mp) row[j0 + i] = ev[i];
+            } else if (j0 >= 1024) {                 // en[tau] = e[1024 + tau] - e[tau]
+                const int t0 = j0 - 1024;
+                if (t0 + 7 <= mp) {
+                    float4 lo0 = *reinterpret_cast<float4 *>(row + t0), lo1 = *reinterpret_cast<float4 *>(row + t0 + 4);
+                    lo0 = make_float4(ev[0] - lo0.x, ev[1] - lo0.y, ev[2] - lo0.z, ev[3] - lo0.w);
+                    lo1 = make_float4(ev[4] - lo1.x, ev[5] - lo1.y, ev[6] - lo1.z, ev[7] - lo1.w);
+                    *reinterpret_cast<float4 *>(row + t0) = lo0;
+                    *reinterpret_cast<float4 *>(row + t0 + 4) = lo1;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) if (t0 + i <= mp) row[t0 + i] = ev[i] - row[t0 + i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = nv[i];
+        }
     }
-    __syncthreads();
-    const double *__restrict__ acf = p.acf + f * (int64_t)p.lag_stride;
-    float en0 = ehi[0] - elo[0];
-    if (fabsf(en0) < 1e-6f) en0 = 0.0f;
-    for (int tau = tid; tau <= mp; tau += 128) {
-        float en = ehi[tau] - elo[tau];
-        if (fabsf(en) < 1e-6f) en = 0.0f;
-        double a = acf[tau];
-        if (fabs(a) < 1e-6) a = 0.0;
-        const float esum = en0 + en;
-        dd[tau] = (double)esum - 2.0 * a;
+    // (the first barrier of the frame loop publishes the rows)
+
+    for (int pr = 0; pr < nfr; pr += 2) {
+        double2 P[2][5];
+        int64_t fidx[2] = {0, 0};
+        bool flive[2] = {false, false};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+            for (int r = 0; r < 5; ++r) P[h][r] = make_double2(0.0, 0.0);
+            if (pr + h >= nfr) continue;                      // odd tail: the pair's second frame does not exist (uniform)
+            const bool live = geo.live;
+            const int c = geo.c;
+            const int64_t f = geo.f;
+            fidx[h] = f; flive[h] = live;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xs[tid + r * 256] = nx[r];
+            geo = locate(pr + h + 1);
+            fetch(geo, nx);                                   // in flight under everything below
+            __syncthreads();
+
+            // ---- feature.rms: np.mean(np.square(x), axis=-2) then sqrt, float32, NumPy's pairwise order -------
+            if (want_rms && tid < 128) {
+                const int bb = tid >> 3, a = tid & 7;
+                const float *xb = xs + bb * 128 + a;
+                float r = xb[0] * xb[0];
+#pragma unroll
+                for (int i = 1; i < 16; ++i) { const float v = xb[8 * i]; r = r + v * v; }
+                red[tid] = r;
+            }
+            if (!want_fft) {
+                __syncthreads();
+                if (want_rms && tid < 16) {
+                    const float *r = red + tid * 8;
+                    blk[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                }
+                __syncthreads();
+            } else {
+                // ---- packed forward FFT of (frame, reversed first half); pass 1 straight from the frame ----
+                double2 v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const int i = tid + 256 * q;
+                    v[q] = make_double2((double)xs[i], i < 1024 ? (double)xs[1024 - i] : 0.0);
+                }
+                fft8_pass1_write(z, tid, v);
+                __syncthreads();
+                if (want_rms && tid < 16) {
+                    const float *r = red + tid * 8;
+                    blk[tid] = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+                }
+                fft8_read8(z, tid, v);
+                __syncthreads();
+                fft8_pass_write<8>(z, tid, v, twr.p2);
+                __syncthreads();
+                fft8_read8(z, tid, v);
+                __syncthreads();
+                fft8_pass_write<64>(z, tid, v, twr.p3);
+                __syncthreads();
+                fft8_pass4(z, tid, twr);
+                __syncthreads();
+            }
+            if (want_rms && tid == 0 && live) {
+                float b0 = (blk[0] + blk[1]) + (blk[2] + blk[3]);
+                float b1 = (blk[4] + blk[5]) + (blk[6] + blk[7]);
+                float b2 = (blk[8] + blk[9]) + (blk[10] + blk[11]);
+                float b3 = (blk[12] + blk[13]) + (blk[14] + blk[15]);
+                const float total = 0.0f + ((b0 + b1) + (b2 + b3));
+                p.out_rms[f] = sqrtf(total / 2048.0f);
+            }
+            if (!want_fft) continue;
+
+            // ---- A[k] = FFT(x)[k], B[k] = FFT(b)[k] from Z by symmetry; P = A*B; windowed power from A ----------
+            auto Aof = [&](int k) {                  // k taken modulo 2048: A[-1] = conj(A[1]), A[1025] = conj(A[1023])
+                const double2 zk = z[zsw(k & 2047)], zn = z[zsw((2048 - k) & 2047)];
+                return make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
+            };
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int k = tid + r * 256;
+                if (k <= 1024) {
+                    const double2 zk = z[zsw(k)], zn = z[zsw((2048 - k) & 2047)];
+                    const double2 A = make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
+                    if (want_pyin) {
+                        const double2 Bv = make_double2((zk.y + zn.y) * 0.5, (zn.x - zk.x) * 0.5);
+                        P[h][r] = c_mul(A, Bv);
+                    }
+                    if (want_mel) {
+                        const double2 am = Aof(k - 1), ap = Aof(k + 1);
+                        const float re = (float)(0.5 * A.x - 0.25 * (am.x + ap.x));
+                        const float im = (float)(0.5 * A.y - 0.25 * (am.y + ap.y));
+                        const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
+                        pw[k] = mag * mag;
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- mel projection: sparse Slaney triangles, float32 fma chain per band; clip maximum --------------
+            if (want_mel && wid < 2) {
+                float acc = 0.0f;
+                if (tid < p.n_mels && live) {
+                    const int s0 = tb.mel_start[tid], len = tb.mel_len[tid];
+                    const float *w = tb.mel_w + tb.mel_off[tid];
+                    for (int i = 0; i < len; ++i) acc = fmaf(w[i], pw[s0 + i], acc);
+                    p.melpow[f * p.n_mels + tid] = acc;
+                }
+                float m = acc;                       // powers are >= 0: float order == unsigned order of the bits
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                if (lane == 0 && live) atomicMax(&p.clipmax[c], __float_as_uint(m));
+            }
+        }
+        if (!want_pyin) continue;
+
+        // ---- one inverse FFT for both frames: conj(Q), Q = Hermitian extension of P0 + i*P1 ---------------------
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            const int k = tid + r * 256;
+            if (k <= 1024) {
+                const double2 u = P[0][r], v = P[1][r];
+                z[zsw(k)] = make_double2(u.x - v.y, -u.y - v.x);                          // conj(P0) - i conj(P1)
+                if (k > 0 && k < 1024) z[zsw(2048 - k)] = make_double2(u.x + v.y, u.y - v.x);   // P0 - i P1
+            }
+        }
+        __syncthreads();
+        {
+            double2 v[8];
+            fft8_read8(z, tid, v);
+            __syncthreads();
+            fft8_pass1_write(z, tid, v);
+            __syncthreads();
+            fft8_read8(z, tid, v);
+            __syncthreads();
+            fft8_pass_write<8>(z, tid, v, twr.p2);
+            __syncthreads();
+            fft8_read8(z, tid, v);
+            __syncthreads();
+            fft8_pass_write<64>(z, tid, v, twr.p3);
+            __syncthreads();
+            fft8_pass4(z, tid, twr);
+            __syncthreads();
+        }
+        // FFT(conj Q) = N * conj(acf0 + i acf1); difference function with librosa's clamps (pitch.py::_cumulative_mean_normalized_difference)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!flive[h]) continue;
+            const float *row = en + (pr + h) * en_stride;
+            float en0 = row[0];
+            if (fabsf(en0) < 1e-6f) en0 = 0.0f;
+            double *__restrict__ drow = p.dfn + fidx[h] * (int64_t)p.lag_stride;
+            for (int tau = tid; tau <= mp; tau += 256) {
+                const double2 zz = z[zsw(1024 + tau)];
+                double a = (h == 0 ? zz.x : -zz.y) * (1.0 / 2048.0);
+                if (fabs(a) < 1e-6) a = 0.0;
+                float e = row[tau];
+                if (fabsf(e) < 1e-6f) e = 0.0f;
+                const float esum = en0 + e;
+                drow[tau] = (double)esum - 2.0 * a;
+            }
+        }
+        // the next pair's first write into z (pass 1) comes after that frame's first barrier
     }
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int tau = 1; tau <= mp; ++tau) { s = (tau == 1) ? dd[1] : s + dd[tau]; cs[tau] = s; }
-    }
-    __syncthreads();
-    double *__restrict__ yin = p.yin + f * (int64_t)p.yin_stride;
-    for (int tau = p.min_period + tid; tau <= mp; tau += 128)
-        yin[tau - p.min_period] = dd[tau] / (cs[tau] / (double)tau + DBL_MIN);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -494,16 +372,18 @@ __device__ __forceinline__ int wave_min_i32(int v) {   // uniform result
 }
 
 __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb) {
-    // dynamic LDS: y[max(n_lags, n_bins)] (reused as the output row), th[KM], tp[KM], ti[KM], tbin[KM], twin[KM]
+    // dynamic LDS: y[max(n_lags, n_bins)] (reused as the output row), th[KM], tp[KM], dd[max_period + 1], ti[KM], tbin[KM], twin[KM]
     extern __shared__ __align__(16) unsigned char osm[];
     const int nl = p.n_lags, B = p.n_bins;
     const int KM = nl / 2 + 2;
     const int YN = (max(nl, B) + 1) & ~1;
+    const int DN = (p.max_period + 2) & ~1;
     double *y = reinterpret_cast<double *>(osm);
     double *row = y;                       // written only after the last read of y
     double *th = y + YN;
     double *tp = th + KM;
-    int16_t *ti = reinterpret_cast<int16_t *>(tp + KM);
+    double *dd = tp + KM;
+    int16_t *ti = reinterpret_cast<int16_t *>(dd + DN);
     int16_t *tbin = ti + KM;
     uint8_t *twin = reinterpret_cast<uint8_t *>(tbin + KM);
     __shared__ double beta_s[104];
@@ -516,9 +396,32 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         int64_t t;
         map_frame(p, (int64_t)blockIdx.x, c, t, f);
     }
-    const double *__restrict__ yr = p.yin + f * (int64_t)p.yin_stride;
-    for (int i = lane; i < nl; i += 64) y[i] = yr[i];
+    // Cumulative-mean-normalised difference (pitch.py::_cumulative_mean_normalized_difference) from the difference
+    // function the frame stage left in HBM: yin[tau] = d[tau] / (cumsum(d[1:])[tau] / tau + tiny).  np.cumsum is strictly
+    // sequential in float64, so ONE lane walks it (the other waves of the CU cover its latency); the quotients run on
+    // all lanes.  The CMND itself never leaves the CU.
+    const int mp = p.max_period, minp = p.min_period;
+    const double *__restrict__ dr = p.dfn + f * (int64_t)p.lag_stride;
+    for (int i = lane; i <= mp; i += 64) dd[i] = dr[i];
     for (int i = lane; i < 100; i += 64) beta_s[i] = tb.beta_probs[i];
+    __syncthreads();
+    if (lane == 0) {
+        double cs = 0.0;
+        for (int tau = 1; tau <= mp; ++tau) {
+            cs = (tau == 1) ? dd[1] : cs + dd[tau];
+            if (tau >= minp) y[tau - minp] = cs;
+        }
+    }
+    __syncthreads();
+    for (int i = lane; i < nl; i += 64) {
+        const int tau = i + minp;
+        y[i] = dd[tau] / (y[i] / (double)tau + DBL_MIN);
+    }
+    if (p.yin != nullptr) {                 // stage-level parity tests only (AEGIS_DEBUG_STAGES=1)
+        __syncthreads();
+        double *__restrict__ yo = p.yin + f * (int64_t)p.yin_stride;
+        for (int i = lane; i < nl; i += 64) yo[i] = y[i];
+    }
     __syncthreads();
 
     // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
@@ -1535,8 +1438,6 @@ void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-constexpr size_t kFrameLds = (size_t)4 * 2048 * 16 + (2 * 2048 + 2 * 1032 + 2 * 128 + 2 * 16) * 4 + 16;
-
 static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
     const int S = 2 * p.n_bins, SP = (S + 63) & ~63;
     size_t b = ((size_t)(2 * SP + 32) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16 * 16;
@@ -1545,7 +1446,7 @@ static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
 }
 
 hipError_t viterbi_configure() {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(frame_fft_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(frame_yin_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
@@ -1558,24 +1459,23 @@ hipError_t viterbi_configure() {
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-void launch_frame_fft(const PassParams &p, const DevTables &t, hipStream_t s) {
+void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0 || !(p.stages & 0xFu)) return;
-    const int64_t pairs = (p.n_sel + 1) / 2;
-    const int g = pairs >= 2048 ? kFramePairs : 1;       // below ~8 workgroups per CU latency matters more than amortisation
-    hipLaunchKernelGGL(frame_fft_kernel, dim3((unsigned)((pairs + g - 1) / g)), dim3(512), kFrameLds, s, p, t, g);
-}
-void launch_yin_seq(const PassParams &p, const DevTables &, hipStream_t s) {
-    if (p.n_sel == 0) return;
-    if (p.n_sel <= 32) {     // a streaming push: a handful of frames, latency matters
-        hipLaunchKernelGGL(yin_seq_wave_kernel, dim3((unsigned)p.n_sel), dim3(128), 0, s, p);
-        return;
+    const int stride = frame_en_stride(p.max_period);
+    // batch launches: as many frames per workgroup as keep two workgroups on a CU (16 at the reference's rates); the
+    // running-energy prologue is one serial walk per workgroup, so small launches (streaming pushes) take a pair each
+    int fpw = 2;
+    if (p.n_sel >= 4096) {
+        fpw = kFramesPerWg;
+        while (fpw > 2 && kFrameLdsFixed + (size_t)fpw * stride * 4 > 80 * 1024) fpw -= 2;
     }
-    hipLaunchKernelGGL(yin_seq_kernel, dim3((unsigned)((p.n_sel + 63) / 64)), dim3(64), 0, s, p);
+    const size_t lds = kFrameLdsFixed + (size_t)fpw * stride * 4;
+    hipLaunchKernelGGL(frame_yin_kernel, dim3((unsigned)((p.n_sel + fpw - 1) / fpw)), dim3(256), lds, s, p, t, fpw, stride);
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0) return;
-    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1;
-    const size_t lds = (size_t)(YN + 2 * KM) * 8 + (size_t)KM * 5 + 16;
+    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1, DN = (p.max_period + 2) & ~1;
+    const size_t lds = (size_t)(YN + 2 * KM + DN) * 8 + (size_t)KM * 5 + 16;
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_sel), dim3(64), lds, s, p, t);
 }
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {

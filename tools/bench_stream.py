@@ -8,6 +8,9 @@ from spectrogram_midi_amd import _lib, signals
 n_push = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 y = signals.guitar_clip(n_push * 2048 / 44100 + 1.0, seed=1)
 h = _lib.Handle()
+if os.environ.get("AEGIS_DUMP_MAPS"):          # address -> library map, to symbolise a crash stack offline
+    with open(os.environ["AEGIS_DUMP_MAPS"], "w") as f:
+        f.write(open("/proc/self/maps").read())
 st = h.open_stream(max_seconds=len(y) / 44100 + 1)
 lat = []
 for i in range(n_push):

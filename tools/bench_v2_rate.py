@@ -14,4 +14,4 @@ h.set_profiling(True)
 ts = []
 for _ in range(2):
     t0 = time.perf_counter(); h.analyze_batch(clips, want_sdb=False); ts.append(time.perf_counter() - t0)
-print("22.05k: s/step", min(ts), "audio-s/s", 64 * 180 / min(ts), {k: round(h.kernel_ms(k), 1) for k in ("frame_fft", "yin_seq", "pyin_obs", "viterbi", "finalize")})
+print("22.05k: s/step", min(ts), "audio-s/s", 64 * 180 / min(ts), {k: round(h.kernel_ms(k), 1) for k in ("frame", "pyin_obs", "viterbi", "finalize")})

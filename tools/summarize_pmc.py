@@ -2,7 +2,7 @@
 `bench.py --steps S --warmup W`) into profiles/r1_pmc_hbm.json: KB per bench step and kernel."""
 import collections, csv, json, sys
 
-NAMES = {"frame_fft_kernel": "frame_fft", "yin_seq_kernel": "yin_seq", "pyin_obs_kernel": "pyin_obs",
+NAMES = {"frame_yin_kernel": "frame", "pyin_obs_kernel": "pyin_obs",
          "viterbi_band_kernel": "viterbi", "viterbi_kernel": "viterbi", "decode_kernel": "finalize",
          "db_rake_kernel": "finalize", "rake_runs_kernel": "finalize"}
 
