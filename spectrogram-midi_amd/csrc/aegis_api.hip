@@ -267,6 +267,10 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRT(upload_table(h, t.mel_len, &h->dt.mel_len));
     CRT(upload_table(h, t.mel_off, &h->dt.mel_off));
     CRT(upload_table(h, t.mel_w, &h->dt.mel_w));
+    CRT(upload_table(h, t.mel_chunk_bin, &h->dt.mel_chunk_bin));
+    CRT(upload_table(h, t.mel_chunk_w, &h->dt.mel_chunk_w));
+    CRT(upload_table(h, t.mel_band_chunk, &h->dt.mel_band_chunk));
+    h->dt.mel_chunks = (int32_t)t.mel_chunk_bin.size();
     CRT(upload_table(h, t.thresholds, &h->dt.thresholds));
     CRT(upload_table(h, t.beta_probs, &h->dt.beta_probs));
     CRT(upload_table(h, t.beta_cumsum, &h->dt.beta_cumsum));
@@ -1263,6 +1267,17 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
             std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 2) * 8);
         }
         return 2;
+    }
+    else if (n == "frame_cycles") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {
+            long long v[16];
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, frame_debug_fetch(v));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
+        }
+        return 16;
     }
     else if (n == "viterbi_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;

@@ -13,6 +13,10 @@ struct DevTables {
     const int32_t *mel_len;    // [n_mels]
     const int32_t *mel_off;    // [n_mels]
     const float *mel_w;        // packed triangle weights
+    const int32_t *mel_chunk_bin;   // [n_chunks] first bin of each <= 16-bin chunk of a triangle
+    const float *mel_chunk_w;       // [n_chunks][16]
+    const int32_t *mel_band_chunk;  // [n_mels + 1]
+    int32_t mel_chunks;
     const double *thresholds;  // [101]
     const double *beta_probs;  // [100]
     const double *beta_cumsum; // [101]
@@ -95,6 +99,7 @@ void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, 
 void launch_stream_advance(StreamCtl *ctl, const float *staging, int n_push, float *pcm, int hop, hipStream_t s);
 void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *vprob, const int32_t *live, void *result,
                           hipStream_t s);
+hipError_t frame_debug_fetch(long long *dst);                // frame_yin_kernel section cycles (AEGIS_ABLATE&128)
 hipError_t viterbi_debug_fetch(long long *dst, bool reset);   // per-wave section cycles (zeros unless AEGIS_ABLATE&64)
 hipError_t viterbi_configure();   // raises the dynamic-LDS limit once
 

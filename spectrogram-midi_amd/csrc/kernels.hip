@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace aegis {
@@ -80,23 +81,80 @@ __device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, in
     }
 }
 
-// floats per running-energy row: lags 0..max_period, a multiple of 4 whose quarter is odd, so that the 16-byte
-// accesses of 16 lanes (one row each) fall on 16 distinct bank groups
+// floats per running-energy row: lags 0..max_period rounded up to whole blocks of 8 (the walk stores whole blocks),
+// then to a multiple of 4 whose quarter is odd, so that the 16-byte accesses of 16 lanes (one row each) fall on 16
+// distinct bank groups
 __host__ __device__ inline int frame_en_stride(int max_period) {
-    int s = (max_period + 1 + 3) & ~3;
+    int s = (max_period + 8) & ~7;
     if (((s >> 2) & 1) == 0) s += 4;
     return s;
 }
-constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1032 * 4 + 128 * 4 + 16 * 4;
 
+// One lane's walk of np.cumsum(frame**2) (float32, strictly sequential) in straight-line blocks of 8 samples:
+//   A  j <  8 nA          e[j] stored                      (nA blocks cover lags 0..max_period)
+//   B  8 nA <= j < 1024   chain only
+//   C  j = 1024 + tau     row[tau] = e[1024 + tau] - e[tau]
+// `fetch(j0, a, b)` returns samples j0..j0+7 of the lane's frame; the next block is requested before the current
+// block's eight dependent adds.  The row is over-written in whole blocks (entries past max_period are never read).
+template <typename Fetch>
+__device__ __forceinline__ void energy_walk(Fetch fetch, float *__restrict__ row, int mp) {
+    const int nA = (mp + 8) >> 3;
+    float4 a, b, na, nb;
+    fetch(0, a, b);
+    float e = 0.0f;                 // 0 + x*x == x*x exactly: the first add reproduces np.cumsum's first element
+    int j0 = 0;
+#define AEGIS_CHAIN8(ea, eb)                                                             \
+    { float sq;                                                                          \
+      sq = a.x * a.x; e = e + sq; ea.x = e;  sq = a.y * a.y; e = e + sq; ea.y = e;       \
+      sq = a.z * a.z; e = e + sq; ea.z = e;  sq = a.w * a.w; e = e + sq; ea.w = e;       \
+      sq = b.x * b.x; e = e + sq; eb.x = e;  sq = b.y * b.y; e = e + sq; eb.y = e;       \
+      sq = b.z * b.z; e = e + sq; eb.z = e;  sq = b.w * b.w; e = e + sq; eb.w = e; }
+    for (int k = 0; k < nA; ++k, j0 += 8) {
+        fetch(j0 + 8, na, nb);
+        float4 ea, eb;
+        AEGIS_CHAIN8(ea, eb)
+        *reinterpret_cast<float4 *>(row + j0) = ea;
+        *reinterpret_cast<float4 *>(row + j0 + 4) = eb;
+        a = na; b = nb;
+    }
+    for (; j0 < 1024; j0 += 8) {
+        fetch(j0 + 8, na, nb);
+        float4 ea, eb;
+        AEGIS_CHAIN8(ea, eb)
+        a = na; b = nb;
+    }
+    for (int k = 0; k < nA; ++k, j0 += 8) {
+        fetch(j0 + 8, na, nb);
+        float4 ea, eb;
+        AEGIS_CHAIN8(ea, eb)
+        float *r = row + 8 * k;
+        const float4 lo0 = *reinterpret_cast<const float4 *>(r), lo1 = *reinterpret_cast<const float4 *>(r + 4);
+        *reinterpret_cast<float4 *>(r) = make_float4(ea.x - lo0.x, ea.y - lo0.y, ea.z - lo0.z, ea.w - lo0.w);
+        *reinterpret_cast<float4 *>(r + 4) = make_float4(eb.x - lo1.x, eb.y - lo1.y, eb.z - lo1.z, eb.w - lo1.w);
+        a = na; b = nb;
+    }
+#undef AEGIS_CHAIN8
+}
+constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1040 * 4 + 128 * 4 + 16 * 4 + 256 * 4;
+
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+__device__ long long g_frm_dbg[16];
+#define FRM_TICK(k) { __builtin_amdgcn_s_waitcnt(0); const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
+#else
+#define FRM_TICK(k)
+#endif
 __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTables tb, int frames_per_wg, int en_stride) {
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+    long long facc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, flast = clock64();
+#endif
     extern __shared__ __align__(16) unsigned char fsm[];
     double2 *z = reinterpret_cast<double2 *>(fsm);               // [2048] FFT buffer (swizzled index, fft8.h)
     float *xs = reinterpret_cast<float *>(z + 2048);             // [2048] the frame
-    float *pw = xs + 2048;                                       // [1032] windowed power spectrum
-    float *red = pw + 1032;                                      // [128]  rms partial sums
+    float *pw = xs + 2048;                                       // [1040] windowed power spectrum (1025 bins, zero tail)
+    float *red = pw + 1040;                                      // [128]  rms partial sums
     float *blk = red + 128;                                      // [16]
-    float *en = blk + 16;                                        // [frames_per_wg][en_stride] running energies
+    float *part = blk + 16;                                      // [256]  mel partial sums, one per 16-bin chunk of a triangle
+    float *en = part + 256;                                      // [frames_per_wg][en_stride] running energies
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t n_sel = geo_n_sel(p);
@@ -134,50 +192,53 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
     Fft8Tw twr;
     if (want_fft) fft8_load_twiddles(twr, tb.twiddle, tid);
 
+    // mel: thread t owns chunk t of the filterbank (<= 16 consecutive bins of one triangle) and, for t < n_mels, band t
+    const bool has_chunk = want_mel && tid < tb.mel_chunks;
+    const int mel_bin = has_chunk ? tb.mel_chunk_bin[tid] : 0;
+    int band_c0 = 0, band_c1 = 0;
+    if (want_mel && tid < p.n_mels) { band_c0 = tb.mel_band_chunk[tid]; band_c1 = tb.mel_band_chunk[tid + 1]; }
+    if (tid < 15) pw[1025 + tid] = 0.0f;         // the last chunks read (zero-weighted) bins past 1024
+
     // ---- prologue: running energy of every frame of the workgroup, one frame per lane ------------------------
-    if (want_pyin && wid == 0 && lane < nfr) {
-        const Geo g = locate(lane);
-        const float *__restrict__ x = p.pcm + g.base;
-        // float4 loads need 16-byte aligned addresses: clip base and hop multiples of 4 samples
-        const bool vec_ok = ((g.base & 3) == 0) && ((p.hop & 3) == 0);
-        float *row = en + lane * en_stride;
-        float v[8], nv[8];
-        load8(x, g.n, g.start, vec_ok, v);
-        float e = 0.0f;
-        const int jend = 1024 + mp + 1;              // e[j] is needed for j <= 1024 + max_period
-        for (int j0 = 0; j0 < jend; j0 += 8) {
-            if (j0 + 8 < jend) load8(x, g.n, g.start + j0 + 8, vec_ok, nv);
-            float ev[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float sq = v[i] * v[i];
-                e = (j0 + i == 0) ? sq : e + sq;     // np.cumsum: strictly sequential float32 adds
-                ev[i] = e;
+    if (want_pyin) {
+        // The workgroup's frames are normally consecutive frames of one clip: their samples (one contiguous stretch,
+        // <= 15 hops + 2048 samples) are staged with coalesced loads in the FFT buffer + frame area, which nothing
+        // uses yet, so the serial walk reads LDS instead of waiting for a global load per eight samples.
+        const Geo g0 = locate(0), gl = locate(nfr - 1);
+        const int64_t span = (int64_t)(nfr - 1) * p.hop + 2048;
+        const bool staged = g0.c == gl.c && p.hop == 512 && span + 4 * (span >> 9) <= 10240;
+        float *stage = reinterpret_cast<float *>(z);
+        if (staged) {                                // sample i sits at i + 4 (i / 512): the lanes' frames start one hop apart,
+            for (int i = tid; i < (int)span; i += 256) {     // the skew puts their 16-byte reads on distinct bank groups
+                const int64_t idx = g0.start + i;
+                stage[i + 4 * (i >> 9)] = (idx >= 0 && idx < g0.n) ? p.pcm[g0.base + idx] : 0.0f;
             }
-            if (j0 + 7 <= mp) {                      // e[tau], tau <= max_period: kept for the subtraction below
-                *reinterpret_cast<float4 *>(row + j0) = make_float4(ev[0], ev[1], ev[2], ev[3]);
-                *reinterpret_cast<float4 *>(row + j0 + 4) = make_float4(ev[4], ev[5], ev[6], ev[7]);
-            } else if (j0 <= mp) {
-#pragma unroll
-                for (int i = 0; i < 8; ++i) if (j0 + i <= mp) row[j0 + i] = ev[i];
-            } else if (j0 >= 1024) {                 // en[tau] = e[1024 + tau] - e[tau]
-                const int t0 = j0 - 1024;
-                if (t0 + 7 <= mp) {
-                    float4 lo0 = *reinterpret_cast<float4 *>(row + t0), lo1 = *reinterpret_cast<float4 *>(row + t0 + 4);
-                    lo0 = make_float4(ev[0] - lo0.x, ev[1] - lo0.y, ev[2] - lo0.z, ev[3] - lo0.w);
-                    lo1 = make_float4(ev[4] - lo1.x, ev[5] - lo1.y, ev[6] - lo1.z, ev[7] - lo1.w);
-                    *reinterpret_cast<float4 *>(row + t0) = lo0;
-                    *reinterpret_cast<float4 *>(row + t0 + 4) = lo1;
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) if (t0 + i <= mp) row[t0 + i] = ev[i] - row[t0 + i];
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) v[i] = nv[i];
+            __syncthreads();
         }
+        if (wid == 0 && lane < nfr) {
+            float *row = en + lane * en_stride;
+            if (staged) {
+                const float *srow = stage + lane * (512 + 4);
+                energy_walk([&](int j, float4 &a, float4 &b) {
+                    const float *q = srow + j + 4 * (j >> 9);                // j + 8 <= 1024 + 8 nA + 8 < 2048: inside the frame
+                    a = *reinterpret_cast<const float4 *>(q);
+                    b = *reinterpret_cast<const float4 *>(q + 4);
+                }, row, mp);
+            } else {                                         // frames of two clips, or a hop the staging area cannot hold
+                const Geo g = locate(lane);
+                const float *__restrict__ x = p.pcm + g.base;
+                energy_walk([&](int j, float4 &a, float4 &b) {
+                    float v[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) { const int64_t q = g.start + j + i; v[i] = (q >= 0 && q < g.n) ? x[q] : 0.0f; }
+                    a = make_float4(v[0], v[1], v[2], v[3]); b = make_float4(v[4], v[5], v[6], v[7]);
+                }, row, mp);
+            }
+        }
+        if (staged) __syncthreads();                     // the staging area becomes the FFT buffer and the frame again
     }
     // (the first barrier of the frame loop publishes the rows)
+    FRM_TICK(0)
 
     for (int pr = 0; pr < nfr; pr += 2) {
         double2 P[2][5];
@@ -197,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             geo = locate(pr + h + 1);
             fetch(geo, nx);                                   // in flight under everything below
             __syncthreads();
+            FRM_TICK(1)
 
             // ---- feature.rms: np.mean(np.square(x), axis=-2) then sqrt, float32, NumPy's pairwise order -------
             if (want_rms && tid < 128) {
@@ -239,6 +301,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 fft8_pass4(z, tid, twr);
                 __syncthreads();
             }
+            FRM_TICK(2)
             if (want_rms && tid == 0 && live) {
                 float b0 = (blk[0] + blk[1]) + (blk[2] + blk[3]);
                 float b1 = (blk[4] + blk[5]) + (blk[6] + blk[7]);
@@ -274,13 +337,25 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 }
             }
             __syncthreads();
-            // ---- mel projection: sparse Slaney triangles, float32 fma chain per band; clip maximum --------------
+            FRM_TICK(3)
+            // ---- mel projection: sparse Slaney triangles.  Every <= 16-bin chunk of a triangle is one thread's float32
+            // fma chain; a band then adds its chunks' sums in order (the widest band has six).  Clip maximum.
+            if (has_chunk) {
+                const float4 *wp = reinterpret_cast<const float4 *>(tb.mel_chunk_w) + tid * 4;
+                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+                const float *pp = pw + mel_bin;
+                float acc = 0.0f;
+                acc = fmaf(w0.x, pp[0], acc); acc = fmaf(w0.y, pp[1], acc); acc = fmaf(w0.z, pp[2], acc); acc = fmaf(w0.w, pp[3], acc);
+                acc = fmaf(w1.x, pp[4], acc); acc = fmaf(w1.y, pp[5], acc); acc = fmaf(w1.z, pp[6], acc); acc = fmaf(w1.w, pp[7], acc);
+                acc = fmaf(w2.x, pp[8], acc); acc = fmaf(w2.y, pp[9], acc); acc = fmaf(w2.z, pp[10], acc); acc = fmaf(w2.w, pp[11], acc);
+                acc = fmaf(w3.x, pp[12], acc); acc = fmaf(w3.y, pp[13], acc); acc = fmaf(w3.z, pp[14], acc); acc = fmaf(w3.w, pp[15], acc);
+                part[tid] = acc;
+            }
+            if (want_mel) __syncthreads();
             if (want_mel && wid < 2) {
                 float acc = 0.0f;
                 if (tid < p.n_mels && live) {
-                    const int s0 = tb.mel_start[tid], len = tb.mel_len[tid];
-                    const float *w = tb.mel_w + tb.mel_off[tid];
-                    for (int i = 0; i < len; ++i) acc = fmaf(w[i], pw[s0 + i], acc);
+                    for (int cidx = band_c0; cidx < band_c1; ++cidx) acc = (cidx == band_c0) ? part[cidx] : acc + part[cidx];
                     p.melpow[f * p.n_mels + tid] = acc;
                 }
                 float m = acc;                       // powers are >= 0: float order == unsigned order of the bits
@@ -288,6 +363,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
                 if (lane == 0 && live) atomicMax(&p.clipmax[c], __float_as_uint(m));
             }
+            FRM_TICK(4)
         }
         if (!want_pyin) continue;
 
@@ -319,6 +395,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             fft8_pass4(z, tid, twr);
             __syncthreads();
         }
+        FRM_TICK(5)
         // FFT(conj Q) = N * conj(acf0 + i acf1); difference function with librosa's clamps (pitch.py::_cumulative_mean_normalized_difference)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -338,8 +415,17 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             }
         }
         // the next pair's first write into z (pass 1) comes after that frame's first barrier
+        FRM_TICK(6)
     }
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+    if (blockIdx.x == 1000 && (tid == 0 || tid == 64)) { for (int k = 0; k < 7; ++k) g_frm_dbg[(tid ? 8 : 0) + k] = facc[k]; }
+#endif
 }
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
+hipError_t frame_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_frm_dbg), sizeof(long long) * 16); }
+#else
+hipError_t frame_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Kernel 3: one frame per wave.  Troughs of the CMND, the Beta/Boltzmann threshold prior,
@@ -372,20 +458,24 @@ __device__ __forceinline__ int wave_min_i32(int v) {   // uniform result
 }
 
 __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb) {
-    // dynamic LDS: y[max(n_lags, n_bins)] (reused as the output row), th[KM], tp[KM], dd[max_period + 1], ti[KM], tbin[KM], twin[KM]
+    // dynamic LDS: y[YN] (CMND, reused as the output row) | U | bfact[KM+1] | bexp[KM+1] | bcum[101], where U holds first
+    // the difference function dd[DN] and later, once the CMND is formed, the trough arrays th[KM], tp[KM], ti[KM], tbin[KM]
     extern __shared__ __align__(16) unsigned char osm[];
     const int nl = p.n_lags, B = p.n_bins;
     const int KM = nl / 2 + 2;
     const int YN = (max(nl, B) + 1) & ~1;
-    const int DN = (p.max_period + 2) & ~1;
+    const int DN = (p.max_period + 1 + 24 + 1) & ~1;      // + look-ahead of the cumsum walk
+    const int UN = max(DN, 2 * KM + (5 * KM + 7) / 8);    // doubles
     double *y = reinterpret_cast<double *>(osm);
     double *row = y;                       // written only after the last read of y
-    double *th = y + YN;
+    double *dd = y + YN;
+    double *th = dd;
     double *tp = th + KM;
-    double *dd = tp + KM;
-    int16_t *ti = reinterpret_cast<int16_t *>(dd + DN);
+    int16_t *ti = reinterpret_cast<int16_t *>(tp + KM);
     int16_t *tbin = ti + KM;
-    uint8_t *twin = reinterpret_cast<uint8_t *>(tbin + KM);
+    double *bfact = dd + UN;               // scipy.stats.boltzmann pieces and the Beta mass prefix sums: every lookup below
+    double *bexp = bfact + (KM + 1);       // is data dependent, so they sit in LDS instead of behind a global load each
+    double *bcum = bexp + (KM + 1);
     __shared__ double beta_s[104];
 
     const int lane = threadIdx.x;
@@ -404,13 +494,40 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     const double *__restrict__ dr = p.dfn + f * (int64_t)p.lag_stride;
     for (int i = lane; i <= mp; i += 64) dd[i] = dr[i];
     for (int i = lane; i < 100; i += 64) beta_s[i] = tb.beta_probs[i];
+    for (int i = lane; i <= KM; i += 64) { bfact[i] = tb.boltz_fact[i]; bexp[i] = tb.boltz_exp[i]; }
+    for (int i = lane; i <= 100; i += 64) bcum[i] = tb.beta_cumsum[i];
     __syncthreads();
     if (lane == 0) {
-        double cs = 0.0;
-        for (int tau = 1; tau <= mp; ++tau) {
-            cs = (tau == 1) ? dd[1] : cs + dd[tau];
-            if (tau >= minp) y[tau - minp] = cs;
+        // Straight-line blocks of 8 lags, the next block's values fetched while the current block's dependent adds
+        // run: the walk is bound by the add latency, not by an LDS round trip (or a branch) per lag.  dd is padded,
+        // so the look-ahead reads stay inside the array.
+        double cs = dd[1];
+        if (minp <= 1) y[1 - minp] = cs;
+        int tau = 2;
+        double cur[8], nxt[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = dd[tau + i];
+        for (; tau + 7 < minp; tau += 8) {               // lags below min_period: no CMND value wanted
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nxt[i] = dd[tau + 8 + i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cs = cs + cur[i];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
         }
+        for (; tau < minp && tau <= mp; ++tau) cs = cs + dd[tau];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = dd[tau + i];
+        for (; tau + 7 <= mp; tau += 8) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nxt[i] = dd[tau + 8 + i];
+            double *yo = y + (tau - minp);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { cs = cs + cur[i]; yo[i] = cs; }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        }
+        for (; tau <= mp; ++tau) { cs = cs + dd[tau]; y[tau - minp] = cs; }
     }
     __syncthreads();
     for (int i = lane; i < nl; i += 64) {
@@ -466,8 +583,10 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
                     if (!(h < 1.0)) g = 100;          // thresholds[100] == 1.0 (also NaN)
                     else if (h <= 0.0) g = 0;
                     else g = (int)(h * 100.0);
-                    while (g < 100 && !(h < tb.thresholds[g + 1])) ++g;
-                    while (g > 0 && h < tb.thresholds[g]) --g;
+                    // thresholds = np.linspace(0, 1, 101): i * 0.01 (one rounding), the last one forced to 1.0
+                    auto thr = [](int i) { return i >= 100 ? 1.0 : (double)i * 0.01; };
+                    while (g < 100 && !(h < thr(g + 1))) ++g;
+                    while (g > 0 && h < thr(g)) --g;
                     jk[q] = g;
                     jmin = min(jmin, g);
                 }
@@ -495,14 +614,14 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
                 }
             }
             nxt = wave_min_i32(nxt);
-            const double fact = tb.boltz_fact[nj];
+            const double fact = bfact[nj];
             double prior[kMaxRounds];
             int before = 0;
 #pragma unroll
             for (int q = 0; q < kMaxRounds; ++q) {
                 prior[q] = 0.0;
                 if (q < rounds) {
-                    if (jk[q] <= j) prior[q] = fact * tb.boltz_exp[before + __popcll(M[q] & lt_mask)];
+                    if (jk[q] <= j) prior[q] = fact * bexp[before + __popcll(M[q] & lt_mask)];
                     before += __popcll(M[q]);
                 }
             }
@@ -533,7 +652,7 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         for (int q = 0; q < kMaxRounds; ++q) {
             if (q < rounds && q * 64 + lane == bk) {
                 const int nb = jk[q] > 100 ? 100 : jk[q];
-                acc[q] = acc[q] + 0.01 * tb.beta_cumsum[nb];
+                acc[q] = acc[q] + 0.01 * bcum[nb];
             }
         }
 
@@ -571,9 +690,12 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         // observation_probs[bin, t] = probs: on duplicate bins the largest lag wins; bins are
         // non-increasing in lag, so a trough loses exactly when the next trough with
         // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
+        bool winq[kMaxRounds];
+        double prq[kMaxRounds];
 #pragma unroll
         for (int q = 0; q < kMaxRounds; ++q) {
             const int k = q * 64 + lane;
+            winq[q] = false; prq[q] = 0.0;
             if (q < rounds && k < K) {
                 const int bin = tbin[k];
                 bool win = false;
@@ -581,20 +703,29 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
                     int k2 = k + 1;
                     while (k2 < K && tbin[k2] < 0) ++k2;
                     win = (k2 >= K) || (tbin[k2] != bin);
-                    if (win) row[bin] = log(tp[k] + DBL_MIN);
+                    if (win) { prq[q] = tp[k]; row[bin] = log(prq[q] + DBL_MIN); }
                 }
-                twin[k] = win ? 1 : 0;
+                winq[q] = win;
             }
         }
-        __syncthreads();
-        // voiced_prob = sum over bins in increasing bin order = decreasing lag order
-        if (lane == 0) {
-            double s = 0.0;
-            for (int k = K - 1; k >= 0; --k)
-                if (twin[k]) s = s + tp[k];
-            vp = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        // voiced_prob = sum over bins in increasing bin order = decreasing lag order: the winners' probabilities are
+        // pulled out of the lanes' registers from the highest trough down (same float64 adds in the same order as a
+        // serial walk, without an LDS round trip per trough)
+        double s = 0.0;
+#pragma unroll
+        for (int q = kMaxRounds - 1; q >= 0; --q) {
+            if (q < rounds) {
+                unsigned long long m = __ballot(winq[q]);
+                while (m) {
+                    const int l = 63 - __clzll((long long)m);
+                    const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(prq[q]), l),
+                                                      __builtin_amdgcn_readlane(__double2loint(prq[q]), l));
+                    s = s + v;
+                    m &= ~(1ull << l);
+                }
+            }
         }
-        vp = __shfl(vp, 0);
+        vp = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
     }
     __syncthreads();
     double *__restrict__ orow = p.logobs + f * (int64_t)p.obs_stride;
@@ -803,7 +934,9 @@ template <int H> __host__ __device__ constexpr int pk_lo_start(int e) { return 1
 template <int H> __host__ __device__ constexpr int pk_int_start() { return 1 + H * (H + 1) + H * (H - 1) / 2; }
 template <int H> __host__ __device__ constexpr int pk_hi_start(int e) { return pk_int_start<H>() + (2 * H + 1) + 2 * H * e - e * (e - 1) / 2; }
 template <int H> __host__ __device__ constexpr int pk_size() { return 3 * H * H + 3 * H + 2; }
-__host__ __device__ constexpr bool band_table_packed(int H) { return H > 25; }
+// The packed layout costs a few scalar multiplies per list entry but 50 KB of LDS instead of 102 at H = 25, which lets a
+// frame-stage workgroup share the CU when the batch fills the chip (256 clips: 240 -> 226 ms); measured neutral at 64 clips.
+__host__ __device__ constexpr bool band_table_packed(int) { return true; }
 
 template <int H>
 struct BandLT {
@@ -1474,10 +1607,20 @@ void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0) return;
-    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1, DN = (p.max_period + 2) & ~1;
-    const size_t lds = (size_t)(YN + 2 * KM + DN) * 8 + (size_t)KM * 5 + 16;
+    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1, DN = (p.max_period + 1 + 24 + 1) & ~1;
+    const int UN = std::max(DN, 2 * KM + (5 * KM + 7) / 8);
+    const size_t lds = (size_t)(YN + UN + 2 * (KM + 1) + 101) * 8 + 16;
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_sel), dim3(64), lds, s, p, t);
 }
+// The Viterbi recurrence is latency-bound on its one CU per clip: any other wave on that CU takes issue slots from it.
+// While the batch leaves CUs free (clips <= exclusive limit, default 128 = half the chip) the launch asks for the whole
+// 160 KB of LDS, so no frame-stage workgroup can be placed beside it; a chip-filling batch asks for what it needs and
+// shares its CUs.  AEGIS_VITERBI_EXCLUSIVE=<clips> moves the limit (0 = never exclusive).
+static size_t viterbi_launch_lds(size_t need, int n_clips) {
+    static const int limit = [] { const char *e = std::getenv("AEGIS_VITERBI_EXCLUSIVE"); return e ? std::atoi(e) : 128; }();
+    return n_clips <= limit ? std::max<size_t>(need, 160 * 1024) : need;
+}
+
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {
     if (p.n_clips == 0) return hipSuccess;
     const int S = 2 * p.n_bins;
@@ -1493,7 +1636,7 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
             }
             blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
             hipLaunchKernelGGL((viterbi_band_kernel<25, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
-                               viterbi_band_lds<25>(p, true), s, p, t, blt);
+                               viterbi_launch_lds(viterbi_band_lds<25>(p, true), p.n_clips), s, p, t, blt);
             return hipGetLastError();
         }
         if (p.half_width == 50 && t.lt_pack != nullptr && viterbi_band_lds<50>(p, true) <= 160 * 1024) {
@@ -1505,7 +1648,7 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
             }
             blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
             hipLaunchKernelGGL((viterbi_band_kernel<50, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
-                               viterbi_band_lds<50>(p, true), s, p, t, blt);
+                               viterbi_launch_lds(viterbi_band_lds<50>(p, true), p.n_clips), s, p, t, blt);
             return hipGetLastError();
         }
     }

@@ -119,6 +119,20 @@ std::string Tables::build(int sr_, int hop_, int n_fft_, int n_mels_, double fmi
         }
     }
 
+    // chunks of <= 16 bins: the frame kernel gives every chunk to one thread (balanced: the widest band has ~85 bins)
+    {
+        mel_chunk_bin.clear(); mel_chunk_w.clear(); mel_band_chunk.assign(n_mels + 1, 0);
+        for (int i = 0; i < n_mels; ++i) {
+            mel_band_chunk[i] = (int32_t)mel_chunk_bin.size();
+            for (int o = 0; o < mel_len[i]; o += 16) {
+                mel_chunk_bin.push_back(mel_start[i] + o);
+                for (int q = 0; q < 16; ++q) mel_chunk_w.push_back(o + q < mel_len[i] ? mel_w[mel_off[i] + o + q] : 0.0f);
+            }
+        }
+        mel_band_chunk[n_mels] = (int32_t)mel_chunk_bin.size();
+        if (mel_chunk_bin.size() > 256) return "mel filterbank needs more than 256 chunks of 16 bins";
+    }
+
     // ---- pYIN priors: thresholds, Beta(2,18) mass per threshold, Boltzmann(2) pieces ----------
     {
         thresholds = np_linspace(0.0, 1.0, kNThresholds + 1);

@@ -33,6 +33,10 @@ struct Tables {
     std::vector<int32_t> mel_len;      // [n_mels] run length of non-zero bins
     std::vector<int32_t> mel_off;      // [n_mels] offset into mel_w
     std::vector<float> mel_w;          // packed non-zero weights
+    // the same triangles cut into chunks of <= 16 consecutive bins (one thread of the frame kernel each, <= 256 chunks):
+    std::vector<int32_t> mel_chunk_bin;    // [n_chunks] first FFT bin
+    std::vector<float> mel_chunk_w;        // [n_chunks][16] weights, zero padded
+    std::vector<int32_t> mel_band_chunk;   // [n_mels + 1] first chunk of each band (prefix)
     std::vector<double> thresholds;    // [101]
     std::vector<double> beta_probs;    // [100]
     std::vector<double> beta_cumsum;   // [101]  np.sum(beta_probs[:n])
