@@ -196,6 +196,7 @@ def parse_args():
     ap.add_argument("--clips", type=int, default=64, help="headline: clips per GPU")
     ap.add_argument("--clip-seconds", type=float, default=180.0)
     ap.add_argument("--folder-clips", type=int, default=512, help="folder: clips in the whole folder")
+    ap.add_argument("--pass-frames", type=int, default=0, help="workspace bound in frames per pass (0 = the library's default)")
     ap.add_argument("--cpu-sample-seconds", type=float, default=240.0, help="oracle sample (A), about 15 s of CPU work")
     ap.add_argument("--cpu-turbo-seconds", type=float, default=120.0, help="oracle sample (B) Turbo Mode; 0 skips it")
     ap.add_argument("--cpu-turbo-cores", type=int, default=0, help="Turbo pool size; 0 = os.cpu_count() like the reference")
@@ -342,7 +343,8 @@ def main():
     audio_seconds = float(n_samples.sum()) / SR
     total_frames = int((n_samples // HOP + 1).sum())
     handle = _lib.Handle(sample_rate=SR, hop_length=HOP, device=local_rank,
-                         max_frames_per_pass=(1 << 21) if args.config == "folder" else max(1 << 21, total_frames))
+                         max_frames_per_pass=args.pass_frames if args.pass_frames > 0 else
+                         (0 if args.config == "folder" else max(1 << 21, total_frames)))
     frame_counts = [handle.frames_for(int(n)) for n in n_samples]
     frames = int(sum(frame_counts))
 

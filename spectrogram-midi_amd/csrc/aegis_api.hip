@@ -35,7 +35,7 @@ struct DevBuf {
 };
 
 struct PassMeta {   // host copies kept alive until the stream has consumed them
-    std::vector<int64_t> sample_off, frame_off, chunk_off, sel_off;
+    std::vector<int64_t> sample_off, sample_len, out_off, frame_off, chunk_off, sel_off;
     std::vector<int32_t> order;
 };
 
@@ -51,14 +51,22 @@ struct aegis_handle {
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
+    // CU-partitioned stream sets of the pipeline (split_streams): [0] Viterbi on 64 CUs / frame stage on 192, [1] 128 / 128
+    struct SplitSet { hipStream_t frame_a = nullptr, frame_b = nullptr, viterbi = nullptr; bool tried = false; } split[2];
+    int split_limit = 64;                     // passes of up to this many clips run partitioned (AEGIS_CU_SPLIT=0 disables)
     hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
     int64_t max_frames_per_pass = 0;
     mutable std::string err;
     std::vector<void *> table_allocs;
-    // workspace (grow-only)
-    DevBuf dfn, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
-    DevBuf sample_off, frame_off, order, sel_off, vstate, vstats;
+    // workspaces (grow-only): passes alternate between the two, so that the frame stage of one pass runs under the
+    // Viterbi of the previous one
+    struct Work {
+        DevBuf dfn, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
+        DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate;
+    } work[2];
+    int last_work = 0;
+    DevBuf vstats, rk_raw;
     CqtBank cqt_bank;
     DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
@@ -116,7 +124,7 @@ namespace {
 int ensure(aegis_handle *h, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return AEGIS_OK;
     if (b.p) {
-        HIPCHK(h, hipStreamSynchronize(h->stream));
+        HIPCHK(h, hipDeviceSynchronize());          // kernels on any of the pipeline's streams may still use the old block
         HIPCHK(h, hipFree(b.p));
         b.p = nullptr; b.cap = 0;
     }
@@ -247,14 +255,15 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
 #define CRTHIP(expr) do { hipError_t e__ = (expr); if (e__ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e__); return fail(AEGIS_ERR_DEVICE); } } while (0)
     CRTHIP(hipSetDevice(c.device));
     CRTHIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    CRTHIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream2, hipStreamNonBlocking));
     CRTHIP(hipStreamCreateWithFlags(&h->stream3, hipStreamNonBlocking));
-    CRTHIP(hipStreamCreateWithFlags(&h->stream4, hipStreamNonBlocking));
     if (const char *e = std::getenv("AEGIS_TIME_CHUNK")) {
         const long v = std::strtol(e, nullptr, 10);
         if (v >= 64 && v % kViterbiChunk == 0) h->time_chunk = v;
     }
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
+    if (const char *e = std::getenv("AEGIS_CU_SPLIT")) h->split_limit = std::atoi(e);
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
     CRT(ensure(h, h->vstats, 16));
@@ -310,6 +319,9 @@ void aegis_destroy(aegis_handle *h) {
 static void destroy_now(aegis_handle *h) noexcept {
     if (h->device < 0) { delete h; return; }
     (void)hipSetDevice(h->device);
+    for (auto &ss : h->split)
+        for (hipStream_t q : {ss.frame_a, ss.frame_b, ss.viterbi})
+            if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     if (h->stream3) (void)hipStreamSynchronize(h->stream3);
@@ -317,9 +329,12 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
-    for (DevBuf *b : {&h->dfn, &h->yin, &h->logobs, &h->logunv, &h->ptr, &h->cmap, &h->chunk_off, &h->bnd,
-                      &h->states, &h->melpow, &h->clipmax, &h->rake_raw, &h->sample_off, &h->frame_off,
-                      &h->order, &h->sel_off, &h->vstate, &h->vstats, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
+    for (auto &w : h->work)
+        for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
+                          &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
+                          &w.vstate})
+            free_buf(*b);
+    for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb})
         free_buf(*b);
@@ -380,6 +395,33 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
     } catch (...) { return abi_fail(h); }
 }
 
+// The Viterbi workgroups (one CU per clip, latency-bound) lose a fifth of their speed when frame-stage workgroups run on
+// NEIGHBOURING compute units: the kernels' code (19 + 31 + 48 KB) does not fit the instruction cache a CU shares with
+// its neighbour (measured: Viterbi 77.5 ms beside the frame stage, 67.9 ms with the frame stage confined to 192 CUs;
+// keeping frame workgroups off the Viterbi's own CU alone changed nothing).  While a batch leaves CUs free the pipeline
+// therefore runs on CU-masked streams: the Viterbi on the last V CUs of the mask, the frame stage on the others.
+static aegis_handle::SplitSet *split_streams(aegis_handle *h, int n_clips) {
+    if (n_clips > h->split_limit || h->split_limit <= 0) return nullptr;
+    // 65..128 clips: a 128 / 128 partition starves the frame stage (170.8 vs 120.9 ms at 128 clips); only reachable
+    // through AEGIS_CU_SPLIT
+    const int idx = n_clips <= 64 ? 0 : 1;
+    if (n_clips > 128) return nullptr;
+    aegis_handle::SplitSet &ss = h->split[idx];
+    if (!ss.tried) {
+        ss.tried = true;
+        const int v = idx == 0 ? 64 : 128;
+        uint32_t fm[8], vm[8];
+        for (int w = 0; w < 8; ++w) { fm[w] = 0; vm[w] = 0; }
+        for (int i = 0; i < 256; ++i) (i < 256 - v ? fm : vm)[i >> 5] |= 1u << (i & 31);
+        if (hipExtStreamCreateWithCUMask(&ss.frame_a, 8, fm) != hipSuccess || hipExtStreamCreateWithCUMask(&ss.frame_b, 8, fm) != hipSuccess ||
+            hipExtStreamCreateWithCUMask(&ss.viterbi, 8, vm) != hipSuccess) {
+            (void)hipGetLastError();
+            for (hipStream_t *q : {&ss.frame_a, &ss.frame_b, &ss.viterbi}) { if (*q) (void)hipStreamDestroy(*q); *q = nullptr; }
+        }
+    }
+    return ss.viterbi ? &ss : nullptr;
+}
+
 static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                  int32_t n_clips, double rake_sensitivity, uint32_t stages,
                                  aegis_outputs *dout, void *stream_v, int32_t sync, HostFeed *feed) {
@@ -393,8 +435,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = stream_v ? static_cast<hipStream_t>(stream_v) : h->stream;
 
-    // per-clip frame counts and validation
-    std::vector<int64_t> frames(n_clips);
+    // per-clip frame counts, validation, and each clip's first frame in the output arrays (caller's clip order)
+    std::vector<int64_t> frames(n_clips), out_first(n_clips);
+    int64_t total_frames = 0;
     for (int i = 0; i < n_clips; ++i) {
         const int64_t n = sample_offsets[i + 1] - sample_offsets[i];
         if (n < 0) { h->err = "sample_offsets must be non-decreasing"; return AEGIS_ERR_INVALID; }
@@ -405,6 +448,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                      std::to_string(h->max_frames_per_pass);
             return AEGIS_ERR_INVALID;
         }
+        out_first[i] = total_frames;
+        total_frames += frames[i];
     }
     // host metadata from earlier calls is no longer referenced once the stream drained
     if (!h->metas.empty()) { HIPCHK(h, hipStreamSynchronize(s)); h->metas.clear(); }
@@ -413,94 +458,64 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     // vision.py:23-25
     const double ms_per_frame = ((double)t.hop / (double)t.sr) * 1000;
     const int rake_min = (int)(10 / ms_per_frame), rake_max = (int)(30 / ms_per_frame);
+    const bool py = stages & AEGIS_STAGE_PYIN;
+    const int S = 2 * t.n_bins;
 
-    int first = 0;
-    int64_t frame_base = 0;   // frames before this pass (for output offsets)
+    // Clips go through the passes LONGEST FIRST (outputs keep the caller's order through out_off): a pass lasts as long
+    // as the Viterbi of its longest clip, so clips of similar length share a pass and no compute unit idles behind a
+    // 330 s clip that happens to sit next to 30 s ones.  Passes alternate between two workspaces, so the frame stage of
+    // pass k+1 runs under the Viterbi of pass k.
+    std::vector<int> by_len(n_clips);
+    std::iota(by_len.begin(), by_len.end(), 0);
+    std::stable_sort(by_len.begin(), by_len.end(), [&](int a, int b) { return frames[a] > frames[b]; });
+
+    while (h->sync_events.size() < 8) {
+        hipEvent_t e;
+        HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        h->sync_events.push_back(e);
+    }
+    // fixed slots of sync_events: 0 call start, 1/2 pass done (workspace parity), 3 frame_b joined, 4 frame_a final, 5.. per chunk
+    enum { EV_START = 0, EV_DONE0 = 1, EV_DONE1 = 2, EV_FB = 3, EV_FA = 4, EV_META = 5, EV_CHUNK0 = 6 };
+
+    int first = 0, pass_index = 0;
+    bool done_recorded[2] = {false, false};
+    std::vector<hipStream_t> joined;          // streams whose work s must wait for before the call returns
     while (first < n_clips) {
         int last = first;
         int64_t fp = 0;
-        while (last < n_clips && fp + frames[last] <= h->max_frames_per_pass) { fp += frames[last]; ++last; }
+        while (last < n_clips && fp + frames[by_len[last]] <= h->max_frames_per_pass) { fp += frames[by_len[last]]; ++last; }
         const int nc = last - first;
+        const int *pc = by_len.data() + first;            // this pass's clips (indices into the caller's arrays)
+        aegis_handle::Work &w = h->work[pass_index & 1];
         h->metas.emplace_back();
         PassMeta &m = h->metas.back();
-        m.sample_off.assign(sample_offsets + first, sample_offsets + last + 1);
-        m.frame_off.resize(nc + 1);
-        m.chunk_off.resize(nc + 1);
+        m.sample_off.resize(nc); m.sample_len.resize(nc); m.out_off.resize(nc);
+        m.frame_off.resize(nc + 1); m.chunk_off.resize(nc + 1);
         m.frame_off[0] = 0; m.chunk_off[0] = 0;
+        int64_t maxF = 0;
         for (int i = 0; i < nc; ++i) {
-            m.frame_off[i + 1] = m.frame_off[i] + frames[first + i];
-            m.chunk_off[i + 1] = m.chunk_off[i] + (frames[first + i] - 1 + kViterbiChunk - 1) / kViterbiChunk;
+            const int ci = pc[i];
+            m.sample_off[i] = sample_offsets[ci];
+            m.sample_len[i] = sample_offsets[ci + 1] - sample_offsets[ci];
+            m.out_off[i] = out_first[ci];
+            m.frame_off[i + 1] = m.frame_off[i] + frames[ci];
+            m.chunk_off[i + 1] = m.chunk_off[i] + (frames[ci] - 1 + kViterbiChunk - 1) / kViterbiChunk;
+            maxF = std::max(maxF, frames[ci]);
         }
         m.order.resize(nc);
-        std::iota(m.order.begin(), m.order.end(), 0);
-        std::stable_sort(m.order.begin(), m.order.end(),
-                         [&](int a, int b) { return frames[first + a] > frames[first + b]; });
+        std::iota(m.order.begin(), m.order.end(), 0);     // already longest first
         const int64_t nchunks = m.chunk_off[nc];
-        const int S = 2 * t.n_bins;
 
-        int rc;
-#define ENS(buf, bytes) if ((rc = ensure(h, h->buf, (size_t)(bytes))) != AEGIS_OK) return rc
-        ENS(sample_off, (nc + 1) * 8); ENS(frame_off, (nc + 1) * 8); ENS(order, nc * 4); ENS(chunk_off, (nc + 1) * 8);
-        if (stages & AEGIS_STAGE_PYIN) {
-            ENS(dfn, fp * h->lag_stride * 8); if (h->debug_stages) ENS(yin, fp * h->yin_stride * 8);
-            ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8);
-            ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
-            ENS(states, fp * 4);
-        }
-        if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
-#undef ENS
-        HIPCHK(h, hipMemcpyAsync(h->sample_off.p, m.sample_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(h->frame_off.p, m.frame_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(h->chunk_off.p, m.chunk_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(h->order.p, m.order.data(), nc * 4, hipMemcpyHostToDevice, s));
-        if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(h->clipmax.p, 0, nc * 4, s));
-
-        PassParams p = base_params(t);
-        p.stages = stages;
-        p.pcm = d_pcm;
-        p.sample_off = static_cast<const int64_t *>(h->sample_off.p);
-        p.frame_off = static_cast<const int64_t *>(h->frame_off.p);
-        p.order = static_cast<const int32_t *>(h->order.p);
-        p.n_clips = nc; p.n_frames = fp;
-        p.dfn = static_cast<double *>(h->dfn.p); p.lag_stride = h->lag_stride;
-        p.yin = ((stages & AEGIS_STAGE_PYIN) && h->debug_stages) ? static_cast<double *>(h->yin.p) : nullptr; p.yin_stride = h->yin_stride;
-        p.logobs = static_cast<double *>(h->logobs.p); p.obs_stride = h->obs_stride;
-        p.logunv = static_cast<double *>(h->logunv.p);
-        p.ptr = static_cast<uint16_t *>(h->ptr.p);
-        p.cmap = static_cast<uint16_t *>(h->cmap.p);
-        p.chunk_off = static_cast<int64_t *>(h->chunk_off.p);
-        p.bnd = static_cast<int32_t *>(h->bnd.p);
-        p.states = static_cast<int32_t *>(h->states.p);
-        p.melpow = static_cast<float *>(h->melpow.p);
-        p.clipmax = static_cast<uint32_t *>(h->clipmax.p);
-        p.rake_raw = static_cast<uint8_t *>(h->rake_raw.p);
-        const bool py = stages & AEGIS_STAGE_PYIN;
-        p.out_f0 = (py && dout->f0) ? dout->f0 + frame_base : nullptr;
-        p.out_voiced = (py && dout->voiced_flag) ? dout->voiced_flag + frame_base : nullptr;
-        p.out_vprob = (py && dout->voiced_prob) ? dout->voiced_prob + frame_base : nullptr;
-        p.out_rms = ((stages & AEGIS_STAGE_RMS) && dout->rms) ? dout->rms + frame_base : nullptr;
-        p.out_rake = ((stages & AEGIS_STAGE_RAKE) && dout->rake_mask) ? dout->rake_mask + frame_base : nullptr;
-        p.out_sdb = ((stages & AEGIS_STAGE_MEL) && dout->S_dB) ? dout->S_dB + (int64_t)t.n_mels * frame_base : nullptr;
-        p.rake_ratio = rake_sensitivity;
-        p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
-
-        // ---- time-chunked pipeline --------------------------------------------------------------
-        // The Viterbi recurrence is sequential in time and occupies one compute unit per clip; the
-        // frame-stage kernels are wide.  Long clips are therefore cut into time chunks of kTimeChunk
-        // Viterbi steps: chunk k's frame stage runs on `s` while chunk k-1's Viterbi runs on the
-        // handle's second stream, carrying its column of values exactly (vstate) across launches.
-        // The frame stage (4.8 us per column of 64 clips) and the Viterbi (5.0 us per step) run at nearly the same
-        // rate, so every growth of the chunk size stalls the Viterbi stream by the extra frame-stage time: chunks
-        // are short and uniform (rocprofv3 timeline: 2048-step chunks behind a 256/768 ramp idled it for 6 ms).
+        // ---- time chunks of the pipeline ---------------------------------------------------------------
+        // The Viterbi recurrence is sequential in time and occupies one compute unit per clip; the frame-stage kernels
+        // are wide.  A pass is therefore cut into time chunks: chunk k's frame stage runs on the frame streams while
+        // chunk k-1's Viterbi runs on the Viterbi stream, carrying its column of values exactly (vstate) across
+        // launches.  Boundaries: frame 0, then 1 + (multiple of kViterbiChunk) so that every launch starts on a
+        // back-pointer-map boundary.  Chunks start at a quarter of time_chunk and grow by 1.25x (the frame stage is
+        // faster than the Viterbi per column, so the Viterbi stream never waits after the first chunk).
         const int64_t kTimeChunk = h->time_chunk;      // multiple of kViterbiChunk
-        int64_t maxF = 0;
-        for (int i = 0; i < nc; ++i) maxF = std::max(maxF, frames[first + i]);
-        // chunk boundaries: frame 0, then 1 + (multiple of kViterbiChunk) so that every launch starts
-        // on a back-pointer-map boundary; nothing overlaps the first (half-size) chunk's frame stage.
         std::vector<int64_t> cb{0};
         if (py && maxF > kTimeChunk + kTimeChunk / 2) {
-            // ramp: the frame stage is ~1.3x faster than the Viterbi per column, so chunks may grow by 1.25x
-            // without ever making the Viterbi stream wait; only the first (quarter-size) chunk is exposed.
             int64_t step = std::max<int64_t>(kViterbiChunk, kTimeChunk / 4 / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
             while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
@@ -515,34 +530,102 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         m.sel_off.assign((size_t)nk * (nc + 1), 0);
         for (int k = 0; k < nk; ++k)
             for (int i = 0; i < nc; ++i) {
-                const int64_t cnt = std::max<int64_t>(0, std::min(frames[first + i], chunk_hi(k)) - chunk_lo(k));
+                const int64_t cnt = std::max<int64_t>(0, std::min(frames[pc[i]], chunk_hi(k)) - chunk_lo(k));
                 m.sel_off[(size_t)k * (nc + 1) + i + 1] = m.sel_off[(size_t)k * (nc + 1) + i] + cnt;
             }
-        if ((rc = ensure(h, h->sel_off, (size_t)nk * (nc + 1) * 8)) != AEGIS_OK) return rc;
-        if (py && (rc = ensure(h, h->vstate, (size_t)nc * S * 8)) != AEGIS_OK) return rc;
-        HIPCHK(h, hipMemcpyAsync(h->sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, s));
-        p.vstate = static_cast<double *>(h->vstate.p);
-        p.vstats = static_cast<unsigned long long *>(h->vstats.p);
-        hipStream_t sv = (nk > 1) ? h->stream2 : s;
+
+        // ---- streams -----------------------------------------------------------------------------------
+        // CU-partitioned streams while the batch leaves compute units free (see split_streams); otherwise the caller's
+        // stream carries the frame stage and the handle's second stream the Viterbi.
+        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v) ? split_streams(h, nc) : nullptr;
+        hipStream_t fa = ss ? ss->frame_a : s;
+        hipStream_t fb = ss ? ss->frame_b : h->stream4;
+        hipStream_t sv = ss ? ss->viterbi : ((py && nk > 1) ? h->stream2 : fa);
         // Large batches are frame-stage bound (every CU carries a Viterbi workgroup): alternating the chunks over two
-        // streams lets chunk k+1's FFTs overlap chunk k's latency-bound YIN / observation kernels (256 clips: 273 -> 259 ms).
-        // Small batches are Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream.
+        // streams lets chunk k+1's FFTs overlap chunk k's latency-bound observation kernel.  Small batches are
+        // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
+        // first four (short) chunks, whose kernels are too small to fill the chip on their own.
         const bool two_fs = py && nk > 2 && nc >= 128;
-        // ... except for the first four (short) chunks, whose kernels are too small to fill the chip on their own: sharing
-        // it shortens the ramp during which the Viterbi stream waits for frames (72.7 -> 71.4 ms; eight chunks: 76 ms).
         const int ramp_k = (py && nk > 2 && !two_fs) ? 4 : 0;
-        while ((int)h->sync_events.size() < nk + 3) {
+        const bool use_fb = two_fs || ramp_k > 0;
+        while ((int)h->sync_events.size() < EV_CHUNK0 + nk) {
             hipEvent_t e;
             HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
             h->sync_events.push_back(e);
         }
-        if (two_fs || ramp_k > 0) {      // everything enqueued on s so far (metadata copies) precedes the second frame stream
-            HIPCHK(h, hipEventRecord(h->sync_events[nk + 1], s));
-            HIPCHK(h, hipStreamWaitEvent(h->stream4, h->sync_events[nk + 1], 0));
+        auto join_later = [&](hipStream_t q) { if (q != s && std::find(joined.begin(), joined.end(), q) == joined.end()) joined.push_back(q); };
+        if (pass_index == 0) HIPCHK(h, hipEventRecord(h->sync_events[EV_START], s));
+        for (hipStream_t q : {fa, fb, sv}) {
+            if (q == s) continue;
+            if (std::find(joined.begin(), joined.end(), q) == joined.end())
+                HIPCHK(h, hipStreamWaitEvent(q, h->sync_events[EV_START], 0));      // the caller's earlier work on s comes first
+            // this workspace was last used two passes ago: everything of that pass must have finished
+            if (done_recorded[pass_index & 1]) HIPCHK(h, hipStreamWaitEvent(q, h->sync_events[EV_DONE0 + (pass_index & 1)], 0));
         }
+        if (fa == s && done_recorded[pass_index & 1]) HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[EV_DONE0 + (pass_index & 1)], 0));
+        join_later(fa); join_later(sv); if (use_fb) join_later(fb);
+
+        // ---- workspace ---------------------------------------------------------------------------------
+        int rc;
+#define ENS(buf, bytes) if ((rc = ensure(h, w.buf, (size_t)(bytes))) != AEGIS_OK) return rc
+        ENS(sample_off, nc * 8); ENS(sample_len, nc * 8); ENS(out_off, nc * 8); ENS(frame_off, (nc + 1) * 8);
+        ENS(order, nc * 4); ENS(chunk_off, (nc + 1) * 8); ENS(sel_off, (size_t)nk * (nc + 1) * 8);
+        if (py) {
+            ENS(dfn, fp * h->lag_stride * 8); if (h->debug_stages) ENS(yin, fp * h->yin_stride * 8);
+            ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8);
+            ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
+            ENS(states, fp * 4); ENS(vstate, (size_t)nc * S * 8);
+        }
+        if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
+#undef ENS
+        HIPCHK(h, hipMemcpyAsync(w.sample_off.p, m.sample_off.data(), nc * 8, hipMemcpyHostToDevice, fa));
+        HIPCHK(h, hipMemcpyAsync(w.sample_len.p, m.sample_len.data(), nc * 8, hipMemcpyHostToDevice, fa));
+        HIPCHK(h, hipMemcpyAsync(w.out_off.p, m.out_off.data(), nc * 8, hipMemcpyHostToDevice, fa));
+        HIPCHK(h, hipMemcpyAsync(w.frame_off.p, m.frame_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, fa));
+        HIPCHK(h, hipMemcpyAsync(w.chunk_off.p, m.chunk_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, fa));
+        HIPCHK(h, hipMemcpyAsync(w.order.p, m.order.data(), nc * 4, hipMemcpyHostToDevice, fa));
+        HIPCHK(h, hipMemcpyAsync(w.sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, fa));
+        if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(w.clipmax.p, 0, nc * 4, fa));
+        if (use_fb) {                    // the metadata precedes the second frame stream's kernels
+            HIPCHK(h, hipEventRecord(h->sync_events[EV_META], fa));
+            HIPCHK(h, hipStreamWaitEvent(fb, h->sync_events[EV_META], 0));
+        }
+
+        PassParams p = base_params(t);
+        p.stages = stages;
+        p.pcm = d_pcm;
+        p.sample_off = static_cast<const int64_t *>(w.sample_off.p);
+        p.sample_len = static_cast<const int64_t *>(w.sample_len.p);
+        p.frame_off = static_cast<const int64_t *>(w.frame_off.p);
+        p.out_off = static_cast<const int64_t *>(w.out_off.p);
+        p.order = static_cast<const int32_t *>(w.order.p);
+        p.n_clips = nc; p.n_frames = fp;
+        p.dfn = static_cast<double *>(w.dfn.p); p.lag_stride = h->lag_stride;
+        p.yin = (py && h->debug_stages) ? static_cast<double *>(w.yin.p) : nullptr; p.yin_stride = h->yin_stride;
+        p.logobs = static_cast<double *>(w.logobs.p); p.obs_stride = h->obs_stride;
+        p.logunv = static_cast<double *>(w.logunv.p);
+        p.ptr = static_cast<uint16_t *>(w.ptr.p);
+        p.cmap = static_cast<uint16_t *>(w.cmap.p);
+        p.chunk_off = static_cast<int64_t *>(w.chunk_off.p);
+        p.bnd = static_cast<int32_t *>(w.bnd.p);
+        p.states = static_cast<int32_t *>(w.states.p);
+        p.melpow = static_cast<float *>(w.melpow.p);
+        p.clipmax = static_cast<uint32_t *>(w.clipmax.p);
+        p.rake_raw = static_cast<uint8_t *>(w.rake_raw.p);
+        p.vstate = static_cast<double *>(w.vstate.p);
+        p.vstats = static_cast<unsigned long long *>(h->vstats.p);
+        p.out_f0 = py ? dout->f0 : nullptr;
+        p.out_voiced = py ? dout->voiced_flag : nullptr;
+        p.out_vprob = py ? dout->voiced_prob : nullptr;
+        p.out_rms = (stages & AEGIS_STAGE_RMS) ? dout->rms : nullptr;
+        p.out_rake = (stages & AEGIS_STAGE_RAKE) ? dout->rake_mask : nullptr;
+        p.out_sdb = (stages & AEGIS_STAGE_MEL) ? dout->S_dB : nullptr;
+        p.rake_ratio = rake_sensitivity;
+        p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
+
         for (int k = 0; k < nk; ++k) {
-            hipStream_t fs = ((two_fs || k < ramp_k) && (k & 1)) ? h->stream4 : s;
-            p.sel_off = static_cast<const int64_t *>(h->sel_off.p) + (size_t)k * (nc + 1);
+            hipStream_t fs = ((two_fs || k < ramp_k) && (k & 1)) ? fb : fa;
+            p.sel_off = static_cast<const int64_t *>(w.sel_off.p) + (size_t)k * (nc + 1);
             p.t_begin = chunk_lo(k);
             p.n_sel = m.sel_off[(size_t)k * (nc + 1) + nc];
             p.vt_begin = chunk_lo(k);
@@ -550,12 +633,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             if (feed) {      // frame t reads samples [t*hop - 1024, t*hop + 1024)
                 bool any = false;
                 for (int i = 0; i < nc; ++i) {
-                    const int64_t n = sample_offsets[first + i + 1] - sample_offsets[first + i];
-                    const int64_t fr = std::min(frames[first + i], chunk_hi(k));
+                    const int ci = pc[i];
+                    const int64_t n = sample_offsets[ci + 1] - sample_offsets[ci];
+                    const int64_t fr = std::min(frames[ci], chunk_hi(k));
                     const int64_t need = (k == nk - 1) ? n : std::min(n, (fr - 1) * (int64_t)t.hop + t.n_fft / 2);
-                    int64_t &done = feed->copied[first + i];
+                    int64_t &done = feed->copied[ci];
                     if (need > done) {
-                        HIPCHK(h, hipMemcpyAsync(feed->dst + sample_offsets[first + i] + done, feed->pcm[first + i] + done,
+                        HIPCHK(h, hipMemcpyAsync(feed->dst + sample_offsets[ci] + done, feed->pcm[ci] + done,
                                                  (size_t)(need - done) * 4, hipMemcpyHostToDevice, h->stream3));
                         done = need;
                         any = true;
@@ -569,9 +653,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             begin_event(h, "frame", fs); launch_frame(p, h->dt, fs); end_event(h, fs);
             if (py) {
                 begin_event(h, "pyin_obs", fs); launch_pyin_obs(p, h->dt, fs); end_event(h, fs);
-                if (nk > 1) {
-                    HIPCHK(h, hipEventRecord(h->sync_events[k], fs));
-                    HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[k], 0));
+                if (sv != fs) {
+                    HIPCHK(h, hipEventRecord(h->sync_events[EV_CHUNK0 + k], fs));
+                    HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0 + k], 0));
                 }
                 begin_event(h, "viterbi", sv);
                 hipError_t ve = launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
@@ -579,23 +663,28 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
             }
         }
-        if (two_fs || ramp_k > 0) {      // the dB / rake finalisation needs every chunk's mel rows and clip maxima
-            HIPCHK(h, hipEventRecord(h->sync_events[nk + 2], h->stream4));
-            HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[nk + 2], 0));
+        if (use_fb) {                    // the dB / rake finalisation needs every chunk's mel rows and clip maxima
+            HIPCHK(h, hipEventRecord(h->sync_events[EV_FB], fb));
+            HIPCHK(h, hipStreamWaitEvent(fa, h->sync_events[EV_FB], 0));
         }
-        begin_event(h, "finalize", s); launch_finalize_mel(p, h->dt, s); end_event(h, s);
-        if (py) {
-            begin_event(h, "finalize", sv); launch_decode(p, h->dt, sv); end_event(h, sv);
-            if (nk > 1) {
-                HIPCHK(h, hipEventRecord(h->sync_events[nk], sv));
-                HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[nk], 0));
-            }
+        begin_event(h, "finalize", fa); launch_finalize_mel(p, h->dt, fa); end_event(h, fa);
+        if (py) { begin_event(h, "finalize", sv); launch_decode(p, h->dt, sv); end_event(h, sv); }
+        // pass done = its last kernels on the frame stream and on the Viterbi stream
+        if (sv != fa) {
+            HIPCHK(h, hipEventRecord(h->sync_events[EV_FA], fa));
+            HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_FA], 0));
         }
+        HIPCHK(h, hipEventRecord(h->sync_events[EV_DONE0 + (pass_index & 1)], sv));
+        done_recorded[pass_index & 1] = true;
         HIPCHK(h, hipGetLastError());
         h->last_frames = fp;
-        frame_base += fp;
+        h->last_work = pass_index & 1;
         first = last;
+        ++pass_index;
     }
+    // the caller's stream continues after everything enqueued above
+    for (int q = 0; q < 2; ++q)
+        if (done_recorded[q]) HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[EV_DONE0 + q], 0));
     if (sync) {
         HIPCHK(h, hipStreamSynchronize(s));
         h->metas.clear();
@@ -663,13 +752,13 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
     int rc;
     const size_t img = (size_t)n_mels * n_frames * 4;
     if ((rc = ensure(h, h->io_sdb, img)) != AEGIS_OK) return rc;
-    if ((rc = ensure(h, h->rake_raw, n_frames)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->rk_raw, n_frames)) != AEGIS_OK) return rc;
     if ((rc = ensure(h, h->io_rake, n_frames)) != AEGIS_OK) return rc;
     hipStream_t s = h->stream;
     HIPCHK(h, hipMemcpyAsync(h->io_sdb.p, S_dB, img, hipMemcpyHostToDevice, s));
     const double ms_per_frame = ((double)h->tab.hop / (double)h->tab.sr) * 1000;   // vision.py:23-25
     launch_rake_from_db(static_cast<const float *>(h->io_sdb.p), n_mels, n_frames, broadband_threshold_ratio,
-                        (int)(10 / ms_per_frame), (int)(30 / ms_per_frame), static_cast<uint8_t *>(h->rake_raw.p),
+                        (int)(10 / ms_per_frame), (int)(30 / ms_per_frame), static_cast<uint8_t *>(h->rk_raw.p),
                         static_cast<uint8_t *>(h->io_rake.p), s);
     HIPCHK(h, hipGetLastError());
     HIPCHK(h, hipMemcpyAsync(mask_out, h->io_rake.p, n_frames, hipMemcpyDeviceToHost, s));
@@ -740,7 +829,7 @@ static PassParams stream_params(aegis_stream *st, const int64_t *dm) {
     PassParams p = base_params(t);
     p.stages = AEGIS_STAGE_ALL;
     p.pcm = static_cast<const float *>(st->pcm.p);
-    p.sample_off = dm; p.frame_off = dm + 2; p.sel_off = dm + 4;
+    p.sample_off = dm; p.sample_len = dm + 1; p.frame_off = dm + 2; p.out_off = dm + 2; p.sel_off = dm + 4;
     p.chunk_off = const_cast<int64_t *>(dm + 6);
     p.order = reinterpret_cast<const int32_t *>(dm + 8);
     p.n_clips = 1;
@@ -990,7 +1079,7 @@ int aegis_stream_close(aegis_stream *st, double rake_sensitivity, aegis_outputs 
     PassParams p = base_params(t);
     p.stages = AEGIS_STAGE_ALL;
     const int64_t *dm = static_cast<const int64_t *>(st->meta.p);
-    p.sample_off = dm; p.frame_off = dm + 2; p.sel_off = dm + 2; p.n_clips = 1; p.n_frames = F; p.n_sel = F;
+    p.sample_off = dm; p.sample_len = dm + 1; p.frame_off = dm + 2; p.out_off = dm + 2; p.sel_off = dm + 2; p.n_clips = 1; p.n_frames = F; p.n_sel = F;
     p.states = static_cast<int32_t *>(st->states.p);
     p.melpow = static_cast<float *>(st->melpow.p); p.clipmax = static_cast<uint32_t *>(st->clipmax.p);
     p.rake_raw = static_cast<uint8_t *>(st->rake_raw.p);
@@ -1249,12 +1338,13 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     const void *src = nullptr;
     int64_t count = 0;
     size_t esz = 8;
-    if (n == "dfn") { src = h->dfn.p; count = F * h->lag_stride; }
-    else if (n == "yin") { src = h->yin.p; count = F * h->yin_stride; }
-    else if (n == "logobs") { src = h->logobs.p; count = F * h->obs_stride; }
-    else if (n == "logunv") { src = h->logunv.p; count = F; }
-    else if (n == "states") { src = h->states.p; count = F; esz = 4; }
-    else if (n == "melpow") { src = h->melpow.p; count = F * h->tab.n_mels; esz = 4; }
+    const aegis_handle::Work &lw = h->work[h->last_work];      // rows in the order the last pass took its clips: longest first
+    if (n == "dfn") { src = lw.dfn.p; count = F * h->lag_stride; }
+    else if (n == "yin") { src = lw.yin.p; count = F * h->yin_stride; }
+    else if (n == "logobs") { src = lw.logobs.p; count = F * h->obs_stride; }
+    else if (n == "logunv") { src = lw.logunv.p; count = F; }
+    else if (n == "states") { src = lw.states.p; count = F; esz = 4; }
+    else if (n == "melpow") { src = lw.melpow.p; count = F * h->tab.n_mels; esz = 4; }
     else if (n == "viterbi_stats" || n == "viterbi_stats_peek") {      // [wave-steps, observed-sources-only wave-steps]
         if (h->device < 0 || !h->vstats.p) return AEGIS_ERR_INVALID;
         if (dst && cap > 0) {

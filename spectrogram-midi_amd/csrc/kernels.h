@@ -51,8 +51,11 @@ struct PassParams {
     uint32_t stages;
     // batch geometry (device arrays are per pass)
     const float *pcm;            // all clips of the batch
-    const int64_t *sample_off;   // [n_clips+1] into pcm (this pass's clips)
-    const int64_t *frame_off;    // [n_clips+1] frame offsets relative to the pass
+    const int64_t *sample_off;   // [n_clips] first sample of each of this pass's clips in pcm
+    const int64_t *sample_len;   // [n_clips] samples per clip
+    const int64_t *frame_off;    // [n_clips+1] frame offsets relative to the pass (workspace rows)
+    const int64_t *out_off;      // [n_clips] first frame of each clip in the OUTPUT arrays (clips keep the caller's order
+                                 //           there, whatever order the passes take them in)
     const int32_t *order;        // [n_clips] clip indices, longest first
     int32_t n_clips;
     int64_t n_frames;            // frames in this pass
@@ -80,9 +83,9 @@ struct PassParams {
     float *melpow;                       // [F][n_mels]
     uint32_t *clipmax;                   // [n_clips]  max mel power (float bits)
     uint8_t *rake_raw;                   // [F]
-    // outputs for this pass (already offset to the pass's first frame; may be null)
+    // outputs of the whole call, indexed through out_off (may be null)
     double *out_f0; uint8_t *out_voiced; double *out_vprob; float *out_rms;
-    uint8_t *out_rake; float *out_sdb;   // out_sdb offset = n_mels * first frame of pass
+    uint8_t *out_rake; float *out_sdb;   // clip c's dB image starts at n_mels * out_off[c]
     double rake_ratio;
     int32_t rake_min_frames, rake_max_frames;
 };

@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 
 namespace aegis {
 
@@ -40,12 +41,14 @@ __device__ __forceinline__ int64_t geo_t_begin(const PassParams &p) { return p.c
 __device__ __forceinline__ int64_t geo_vt_begin(const PassParams &p) { return p.ctl ? p.ctl->vt_begin : p.vt_begin; }
 __device__ __forceinline__ int64_t geo_vt_end(const PassParams &p) { return p.ctl ? p.ctl->vt_end : p.vt_end; }
 
-// selected-frame index of this launch -> (clip, frame within clip, frame within pass)
+// selected-frame index of this launch -> (clip, frame within clip, frame within pass = workspace row)
 __device__ __forceinline__ void map_frame(const PassParams &p, int64_t fs, int &c, int64_t &t, int64_t &f) {
     c = find_clip(p.sel_off, p.n_clips, fs);
     t = geo_t_begin(p) + (fs - p.sel_off[c]);
     f = p.frame_off[c] + t;
 }
+// frame t of clip c in the output arrays
+__device__ __forceinline__ int64_t out_index(const PassParams &p, int c, int64_t t) { return p.out_off[c] + t; }
 
 
 // ------------------------------------------------------------------------------------------
@@ -166,15 +169,16 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
     const bool want_fft = (p.stages & 0x7u) != 0;
     const int mp = p.max_period;
 
-    struct Geo { bool live; int c; int64_t base, n, start, f; };
+    struct Geo { bool live; int c; int64_t base, n, start, f, o; };
     auto locate = [&](int i) {
-        Geo g{false, 0, 0, 0, 0, 0};
+        Geo g{false, 0, 0, 0, 0, 0, 0};
         g.live = i < nfr;
         if (g.live) {
             int64_t t;
             map_frame(p, fs0 + i, g.c, t, g.f);
+            g.o = out_index(p, g.c, t);
             g.base = p.sample_off[g.c];
-            g.n = p.sample_off[g.c + 1] - g.base;
+            g.n = p.sample_len[g.c];
             g.start = t * p.hop - 1024;
         }
         return g;
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             if (pr + h >= nfr) continue;                      // odd tail: the pair's second frame does not exist (uniform)
             const bool live = geo.live;
             const int c = geo.c;
-            const int64_t f = geo.f;
+            const int64_t f = geo.f, fo = geo.o;
             fidx[h] = f; flive[h] = live;
 #pragma unroll
             for (int r = 0; r < 8; ++r) xs[tid + r * 256] = nx[r];
@@ -308,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 float b2 = (blk[8] + blk[9]) + (blk[10] + blk[11]);
                 float b3 = (blk[12] + blk[13]) + (blk[14] + blk[15]);
                 const float total = 0.0f + ((b0 + b1) + (b2 + b3));
-                p.out_rms[f] = sqrtf(total / 2048.0f);
+                p.out_rms[fo] = sqrtf(total / 2048.0f);
             }
             if (!want_fft) continue;
 
@@ -480,11 +484,12 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
 
     const int lane = threadIdx.x;
     if ((int64_t)blockIdx.x >= geo_n_sel(p)) return;
-    int64_t f;
+    int64_t f, fo;
     {
         int c;
         int64_t t;
         map_frame(p, (int64_t)blockIdx.x, c, t, f);
+        fo = out_index(p, c, t);
     }
     // Cumulative-mean-normalised difference (pitch.py::_cumulative_mean_normalized_difference) from the difference
     // function the frame stage left in HBM: yin[tau] = d[tau] / (cumsum(d[1:])[tau] / tau + tiny).  np.cumsum is strictly
@@ -567,173 +572,181 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
 
     double vp = 0.0;
     const int rounds = (K + 63) >> 6;
-    if (K > 0) {
-        int jk[kMaxRounds];
-        double acc[kMaxRounds];
-        int jmin = 101;
-#pragma unroll
-        for (int q = 0; q < kMaxRounds; ++q) {
-            jk[q] = 101; acc[q] = 0.0;
-            if (q < rounds) {
-                const int k = q * 64 + lane;
-                if (k < K) {
-                    // first threshold index j with h < thresholds[j+1]; 100 when none
-                    const double h = th[k];
-                    int g;
-                    if (!(h < 1.0)) g = 100;          // thresholds[100] == 1.0 (also NaN)
-                    else if (h <= 0.0) g = 0;
-                    else g = (int)(h * 100.0);
-                    // thresholds = np.linspace(0, 1, 101): i * 0.01 (one rounding), the last one forced to 1.0
-                    auto thr = [](int i) { return i >= 100 ? 1.0 : (double)i * 0.01; };
-                    while (g < 100 && !(h < thr(g + 1))) ++g;
-                    while (g > 0 && h < thr(g)) --g;
-                    jk[q] = g;
-                    jmin = min(jmin, g);
-                }
-            }
-        }
-        jmin = wave_min_i32(jmin);
-
-        // probs[k] = sum_j [h_k < thr_{j+1}] * boltzmann.pmf(pos_k(j); 2, n_j) * beta_probs[j],
-        // products added in ascending j (the order the oracle fixes for librosa's BLAS dot).
-        // The set of troughs below threshold j only changes where j passes some trough's first
-        // threshold, so the prior is rebuilt at those change points only; inside a stretch every
-        // j still contributes its own rounded product, which keeps the sum bit-identical.
-        const unsigned long long lt_mask = (1ull << lane) - 1ull;
-        int j = jmin;
-        while (j < 100) {
-            unsigned long long M[kMaxRounds];
-            int nj = 0, nxt = 100;
-#pragma unroll
-            for (int q = 0; q < kMaxRounds; ++q) {
-                M[q] = 0ull;
+    // Everything below is unrolled over the rounds of 64 troughs a frame may need (up to 8); nearly every frame has at
+    // most 128 troughs, so the body exists twice: the two-round instance is what runs (a quarter of the code: the three
+    // frame-stage kernels and the Viterbi share instruction caches), the eight-round one covers the rest.
+    auto tail = [&](auto maxr_tag) {
+        constexpr int MAXR = decltype(maxr_tag)::value;
+        if (K > 0) {
+            int jk[MAXR];
+            double acc[MAXR];
+            int jmin = 101;
+    #pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                jk[q] = 101; acc[q] = 0.0;
                 if (q < rounds) {
-                    M[q] = __ballot(jk[q] <= j);
-                    nj += __popcll(M[q]);
-                    if (jk[q] > j) nxt = min(nxt, jk[q]);
-                }
-            }
-            nxt = wave_min_i32(nxt);
-            const double fact = bfact[nj];
-            double prior[kMaxRounds];
-            int before = 0;
-#pragma unroll
-            for (int q = 0; q < kMaxRounds; ++q) {
-                prior[q] = 0.0;
-                if (q < rounds) {
-                    if (jk[q] <= j) prior[q] = fact * bexp[before + __popcll(M[q] & lt_mask)];
-                    before += __popcll(M[q]);
-                }
-            }
-            for (int jj = j; jj < nxt; ++jj) {
-                const double bj = beta_s[jj];
-#pragma unroll
-                for (int q = 0; q < kMaxRounds; ++q)
-                    if (q < rounds) acc[q] = acc[q] + prior[q] * bj;
-            }
-            j = nxt;
-        }
-
-        // global minimum trough (first index on ties) gets the no-trough mass
-        double bh = INFINITY;
-        int bk = kKMax;
-#pragma unroll
-        for (int q = 0; q < kMaxRounds; ++q) {
-            const int k = q * 64 + lane;
-            if (q < rounds && k < K) { const double h = th[k]; if (h < bh) { bh = h; bk = k; } }
-        }
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const double oh = __shfl_xor(bh, o);
-            const int ok = __shfl_xor(bk, o);
-            if (oh < bh || (oh == bh && ok < bk)) { bh = oh; bk = ok; }
-        }
-#pragma unroll
-        for (int q = 0; q < kMaxRounds; ++q) {
-            if (q < rounds && q * 64 + lane == bk) {
-                const int nb = jk[q] > 100 ? 100 : jk[q];
-                acc[q] = acc[q] + 0.01 * bcum[nb];
-            }
-        }
-
-        // parabolic refinement and pitch bin for every trough that carries probability
-#pragma unroll
-        for (int q = 0; q < kMaxRounds; ++q) {
-            const int k = q * 64 + lane;
-            if (q < rounds && k < K) {
-                const double pr = acc[q];
-                int bin = -1;
-                if (pr != 0.0) {
-                    const int i = ti[k];
-                    double shift = 0.0;
-                    if (i > 0 && i < nl - 1) {
-                        const double ym = y[i - 1], y0 = y[i], yp = y[i + 1];
-                        const double a = yp + ym - 2.0 * y0;
-                        const double b = (yp - ym) / 2.0;
-                        if (fabs(b) < fabs(a)) shift = -b / a;
+                    const int k = q * 64 + lane;
+                    if (k < K) {
+                        // first threshold index j with h < thresholds[j+1]; 100 when none
+                        const double h = th[k];
+                        int g;
+                        if (!(h < 1.0)) g = 100;          // thresholds[100] == 1.0 (also NaN)
+                        else if (h <= 0.0) g = 0;
+                        else g = (int)(h * 100.0);
+                        // thresholds = np.linspace(0, 1, 101): i * 0.01 (one rounding), the last one forced to 1.0
+                        auto thr = [](int i) { return i >= 100 ? 1.0 : (double)i * 0.01; };
+                        while (g < 100 && !(h < thr(g + 1))) ++g;
+                        while (g > 0 && h < thr(g)) --g;
+                        jk[q] = g;
+                        jmin = min(jmin, g);
                     }
-                    const double period = (double)(p.min_period + i) + shift;
-                    const double f0c = (double)p.sr / period;
-                    double r = rint(120.0 * log2(f0c / p.fmin));
-                    r = r < 0.0 ? 0.0 : (r > (double)B ? (double)B : r);
-                    bin = (int)r;
-                }
-                tp[k] = pr;
-                tbin[k] = (int16_t)bin;
-            }
-        }
-    }
-    __syncthreads();                 // last read of y is behind us: the buffer becomes the output row
-    for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
-    __syncthreads();
-    if (K > 0) {
-        // observation_probs[bin, t] = probs: on duplicate bins the largest lag wins; bins are
-        // non-increasing in lag, so a trough loses exactly when the next trough with
-        // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
-        bool winq[kMaxRounds];
-        double prq[kMaxRounds];
-#pragma unroll
-        for (int q = 0; q < kMaxRounds; ++q) {
-            const int k = q * 64 + lane;
-            winq[q] = false; prq[q] = 0.0;
-            if (q < rounds && k < K) {
-                const int bin = tbin[k];
-                bool win = false;
-                if (bin >= 0 && bin < B) {
-                    int k2 = k + 1;
-                    while (k2 < K && tbin[k2] < 0) ++k2;
-                    win = (k2 >= K) || (tbin[k2] != bin);
-                    if (win) { prq[q] = tp[k]; row[bin] = log(prq[q] + DBL_MIN); }
-                }
-                winq[q] = win;
-            }
-        }
-        // voiced_prob = sum over bins in increasing bin order = decreasing lag order: the winners' probabilities are
-        // pulled out of the lanes' registers from the highest trough down (same float64 adds in the same order as a
-        // serial walk, without an LDS round trip per trough)
-        double s = 0.0;
-#pragma unroll
-        for (int q = kMaxRounds - 1; q >= 0; --q) {
-            if (q < rounds) {
-                unsigned long long m = __ballot(winq[q]);
-                while (m) {
-                    const int l = 63 - __clzll((long long)m);
-                    const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(prq[q]), l),
-                                                      __builtin_amdgcn_readlane(__double2loint(prq[q]), l));
-                    s = s + v;
-                    m &= ~(1ull << l);
                 }
             }
+            jmin = wave_min_i32(jmin);
+
+            // probs[k] = sum_j [h_k < thr_{j+1}] * boltzmann.pmf(pos_k(j); 2, n_j) * beta_probs[j],
+            // products added in ascending j (the order the oracle fixes for librosa's BLAS dot).
+            // The set of troughs below threshold j only changes where j passes some trough's first
+            // threshold, so the prior is rebuilt at those change points only; inside a stretch every
+            // j still contributes its own rounded product, which keeps the sum bit-identical.
+            const unsigned long long lt_mask = (1ull << lane) - 1ull;
+            int j = jmin;
+            while (j < 100) {
+                unsigned long long M[MAXR];
+                int nj = 0, nxt = 100;
+    #pragma unroll
+                for (int q = 0; q < MAXR; ++q) {
+                    M[q] = 0ull;
+                    if (q < rounds) {
+                        M[q] = __ballot(jk[q] <= j);
+                        nj += __popcll(M[q]);
+                        if (jk[q] > j) nxt = min(nxt, jk[q]);
+                    }
+                }
+                nxt = wave_min_i32(nxt);
+                const double fact = bfact[nj];
+                double prior[MAXR];
+                int before = 0;
+    #pragma unroll
+                for (int q = 0; q < MAXR; ++q) {
+                    prior[q] = 0.0;
+                    if (q < rounds) {
+                        if (jk[q] <= j) prior[q] = fact * bexp[before + __popcll(M[q] & lt_mask)];
+                        before += __popcll(M[q]);
+                    }
+                }
+                for (int jj = j; jj < nxt; ++jj) {
+                    const double bj = beta_s[jj];
+    #pragma unroll
+                    for (int q = 0; q < MAXR; ++q)
+                        if (q < rounds) acc[q] = acc[q] + prior[q] * bj;
+                }
+                j = nxt;
+            }
+
+            // global minimum trough (first index on ties) gets the no-trough mass
+            double bh = INFINITY;
+            int bk = kKMax;
+    #pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                const int k = q * 64 + lane;
+                if (q < rounds && k < K) { const double h = th[k]; if (h < bh) { bh = h; bk = k; } }
+            }
+    #pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) {
+                const double oh = __shfl_xor(bh, o);
+                const int ok = __shfl_xor(bk, o);
+                if (oh < bh || (oh == bh && ok < bk)) { bh = oh; bk = ok; }
+            }
+    #pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                if (q < rounds && q * 64 + lane == bk) {
+                    const int nb = jk[q] > 100 ? 100 : jk[q];
+                    acc[q] = acc[q] + 0.01 * bcum[nb];
+                }
+            }
+
+            // parabolic refinement and pitch bin for every trough that carries probability
+    #pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                const int k = q * 64 + lane;
+                if (q < rounds && k < K) {
+                    const double pr = acc[q];
+                    int bin = -1;
+                    if (pr != 0.0) {
+                        const int i = ti[k];
+                        double shift = 0.0;
+                        if (i > 0 && i < nl - 1) {
+                            const double ym = y[i - 1], y0 = y[i], yp = y[i + 1];
+                            const double a = yp + ym - 2.0 * y0;
+                            const double b = (yp - ym) / 2.0;
+                            if (fabs(b) < fabs(a)) shift = -b / a;
+                        }
+                        const double period = (double)(p.min_period + i) + shift;
+                        const double f0c = (double)p.sr / period;
+                        double r = rint(120.0 * log2(f0c / p.fmin));
+                        r = r < 0.0 ? 0.0 : (r > (double)B ? (double)B : r);
+                        bin = (int)r;
+                    }
+                    tp[k] = pr;
+                    tbin[k] = (int16_t)bin;
+                }
+            }
         }
-        vp = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
-    }
+        __syncthreads();                 // last read of y is behind us: the buffer becomes the output row
+        for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
+        __syncthreads();
+        if (K > 0) {
+            // observation_probs[bin, t] = probs: on duplicate bins the largest lag wins; bins are
+            // non-increasing in lag, so a trough loses exactly when the next trough with
+            // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
+            bool winq[MAXR];
+            double prq[MAXR];
+    #pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
+                const int k = q * 64 + lane;
+                winq[q] = false; prq[q] = 0.0;
+                if (q < rounds && k < K) {
+                    const int bin = tbin[k];
+                    bool win = false;
+                    if (bin >= 0 && bin < B) {
+                        int k2 = k + 1;
+                        while (k2 < K && tbin[k2] < 0) ++k2;
+                        win = (k2 >= K) || (tbin[k2] != bin);
+                        if (win) { prq[q] = tp[k]; row[bin] = log(prq[q] + DBL_MIN); }
+                    }
+                    winq[q] = win;
+                }
+            }
+            // voiced_prob = sum over bins in increasing bin order = decreasing lag order: the winners' probabilities are
+            // pulled out of the lanes' registers from the highest trough down (same float64 adds in the same order as a
+            // serial walk, without an LDS round trip per trough)
+            double s = 0.0;
+    #pragma unroll
+            for (int q = MAXR - 1; q >= 0; --q) {
+                if (q < rounds) {
+                    unsigned long long m = __ballot(winq[q]);
+                    while (m) {
+                        const int l = 63 - __clzll((long long)m);
+                        const double v = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(prq[q]), l),
+                                                          __builtin_amdgcn_readlane(__double2loint(prq[q]), l));
+                        s = s + v;
+                        m &= ~(1ull << l);
+                    }
+                }
+            }
+            vp = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+        }
+    };
+    if (rounds <= 2) tail(std::integral_constant<int, 2>{});
+    else tail(std::integral_constant<int, kMaxRounds>{});
     __syncthreads();
     double *__restrict__ orow = p.logobs + f * (int64_t)p.obs_stride;
     for (int b = lane; b < B; b += 64) orow[b] = row[b];
     if (lane == 0) {
         const double unv = (1.0 - vp) / (double)B;
         p.logunv[f] = log(unv + DBL_MIN);
-        if (p.out_vprob != nullptr) p.out_vprob[f] = vp;
+        if (p.out_vprob != nullptr) p.out_vprob[fo] = vp;
     }
 }
 
@@ -1111,10 +1124,26 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int lw0 = lrlo >> 6, lw1 = lrhi >> 6;
     int cur = 0;
     int n_list = 0;           // wave-steps that took the observed-sources-only path (wave-uniform)
+#ifdef AEGIS_LP_AHEAD
+    double lpa = 0.0, lpb = 0.0;
+    if (act) {
+        const int ta = min(t_lo, T - 1), tb2 = min(t_lo + 1, T - 1);
+        lpa = vp ? lunv[ta] : lobs[(int64_t)ta * os + b2c];
+        lpb = vp ? lunv[tb2] : lobs[(int64_t)tb2 * os + b2c];
+    }
+#endif
     for (int t = t_lo; t < t_hi; ++t) {
         VIT_TICK(5)
+#ifdef AEGIS_LP_AHEAD
+        // the step's observation was requested two steps ago (a load issued under a busy memory system may take longer
+        // than one step); rows beyond this launch's range are fetched and never used
+        const double lp = lpa;
+        lpa = lpb;
+        { const int tn = min(t + 2, T - 1); if (act) lpb = vp ? lunv[tn] : lobs[(int64_t)tn * os + b2c]; }
+#else
         double lp = 0.0;
         if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
+#endif
         const int lpar = par ^ 1;      // parity the previous end_of_step wrote its lists under
         // observed bins within reach of this wave's targets, [wlo - H, whi + H], span <= 3 mask words: their masks and
         // the voiced waves' largest observed values are fetched here, far ahead of the list section that tests them
@@ -1394,8 +1423,10 @@ __global__ __launch_bounds__(256) void decode_kernel(PassParams p, DevTables tb)
     if (f >= p.n_frames) return;
     const int s = p.states[f];
     const bool voiced = s < p.n_bins;
-    if (p.out_voiced != nullptr) p.out_voiced[f] = voiced ? 1 : 0;
-    if (p.out_f0 != nullptr) p.out_f0[f] = voiced ? tb.freqs[s] : (double)NAN;
+    const int c = find_clip(p.frame_off, p.n_clips, f);
+    const int64_t fo = out_index(p, c, f - p.frame_off[c]);
+    if (p.out_voiced != nullptr) p.out_voiced[fo] = voiced ? 1 : 0;
+    if (p.out_f0 != nullptr) p.out_f0[fo] = voiced ? tb.freqs[s] : (double)NAN;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1450,7 +1481,7 @@ __global__ __launch_bounds__(256) void db_rake_kernel(PassParams p) {
             const int64_t fo = p.frame_off[c];
             const int64_t Fc = p.frame_off[c + 1] - fo;
             const int64_t tl = fb + r - fo;
-            p.out_sdb[(int64_t)nm * fo + (int64_t)m * Fc + tl] = tile[r][m];
+            p.out_sdb[(int64_t)nm * p.out_off[c] + (int64_t)m * Fc + tl] = tile[r][m];
         }
     }
 }
@@ -1475,7 +1506,10 @@ __global__ __launch_bounds__(256) void rake_runs_kernel(PassParams p) {
         const bool closed = e < hi;   // a run still open at the end of the clip is dropped
         if (steps <= lim && closed && len >= p.rake_min_frames && len <= p.rake_max_frames) keep = 1;
     }
-    p.out_rake[f] = keep;
+    {
+        const int c = find_clip(p.frame_off, p.n_clips, f);
+        p.out_rake[out_index(p, c, f - p.frame_off[c])] = keep;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1613,11 +1647,12 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_sel), dim3(64), lds, s, p, t);
 }
 // The Viterbi recurrence is latency-bound on its one CU per clip: any other wave on that CU takes issue slots from it.
-// While the batch leaves CUs free (clips <= exclusive limit, default 128 = half the chip) the launch asks for the whole
-// 160 KB of LDS, so no frame-stage workgroup can be placed beside it; a chip-filling batch asks for what it needs and
-// shares its CUs.  AEGIS_VITERBI_EXCLUSIVE=<clips> moves the limit (0 = never exclusive).
+// AEGIS_VITERBI_EXCLUSIVE=<clips> (experiment knob, default off): launches of up to that many clips ask for the whole 160 KB
+// of LDS, so that no frame-stage workgroup can be placed on the same CU.  Measured: no gain (64 clips: 83.6 vs 78.9 ms) --
+// what slows the Viterbi is frame-stage code on the NEIGHBOURING CU (shared instruction cache), which the CU-partitioned
+// streams of aegis_api.hip::split_streams avoid.
 static size_t viterbi_launch_lds(size_t need, int n_clips) {
-    static const int limit = [] { const char *e = std::getenv("AEGIS_VITERBI_EXCLUSIVE"); return e ? std::atoi(e) : 128; }();
+    static const int limit = [] { const char *e = std::getenv("AEGIS_VITERBI_EXCLUSIVE"); return e ? std::atoi(e) : 0; }();
     return n_clips <= limit ? std::max<size_t>(need, 160 * 1024) : need;
 }
 

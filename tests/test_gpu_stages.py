@@ -36,7 +36,14 @@ def run(stage_handle, test_clips):
     res = gpu_handle.analyze_batch(clips, rake_sensitivity=0.6)
     inter = {k: gpu_handle.debug_fetch(k) for k in ("dfn", "yin", "logobs", "logunv", "states", "melpow")}
     frames = [gpu_handle.frames_for(len(c)) for c in clips]
-    offs = np.concatenate([[0], np.cumsum(frames)])
+    # workspace rows follow the order the pass takes its clips in: longest first (stable); outputs keep the caller's order
+    order = sorted(range(len(clips)), key=lambda i: (-frames[i], i))
+    lo = np.zeros(len(clips), np.int64)
+    pos = 0
+    for i in order:
+        lo[i] = pos
+        pos += frames[i]
+    offs = np.stack([lo, lo + np.array(frames)], axis=1)
     strides = {k: gpu_handle.param(k) for k in ("lag_stride", "yin_stride", "obs_stride")}
     ora = {}
     for k, c in zip(names, clips):
@@ -52,7 +59,7 @@ def run(stage_handle, test_clips):
 
 def _rows(run, key, i, stride, width):
     a = run["inter"][key].reshape(-1, stride)
-    return a[run["offs"][i]: run["offs"][i + 1], :width]
+    return a[run["offs"][i][0]: run["offs"][i][1], :width]
 
 
 def test_frame_counts(run):
@@ -92,7 +99,7 @@ def test_observation(run):
         ref = np.log(obs[:441].T + opyin.TINY)
         assert np.array_equal(got > -700, ref > -700), (k, "observation support differs")
         np.testing.assert_allclose(got, ref, rtol=1e-9, atol=1e-9, err_msg=k)
-        lu = run["inter"]["logunv"][run["offs"][i]: run["offs"][i + 1]]
+        lu = run["inter"]["logunv"][run["offs"][i][0]: run["offs"][i][1]]
         # 1 - voiced_prob cancels to rounding noise when every threshold finds a trough, so
         # the unvoiced observation is compared in the linear domain
         np.testing.assert_allclose(np.exp(lu), obs[441], rtol=1e-9, atol=1e-15, err_msg=k)
@@ -106,7 +113,7 @@ def test_pitch_track_exact(run):
     for i, k in enumerate(run["names"]):
         r, o = run["res"][i], run["ora"][k]
         np.testing.assert_array_equal(r["voiced_flag"], o["vf"], err_msg=k)
-        st = run["inter"]["states"][run["offs"][i]: run["offs"][i + 1]]
+        st = run["inter"]["states"][run["offs"][i][0]: run["offs"][i][1]]
         voiced = o["vf"]
         np.testing.assert_array_equal(st[voiced], o["states"][voiced], err_msg=k)   # pitch bins
         assert np.array_equal(np.isnan(r["f0"]), np.isnan(o["f0"])), k
@@ -115,7 +122,7 @@ def test_pitch_track_exact(run):
 
 def test_mel_and_db(run):
     for i, k in enumerate(run["names"]):
-        got = run["inter"]["melpow"].reshape(-1, 128)[run["offs"][i]: run["offs"][i + 1]].T
+        got = run["inter"]["melpow"].reshape(-1, 128)[run["offs"][i][0]: run["offs"][i][1]].T
         ref = run["ora"][k]["S"]
         tol = 1e-4 * max(ref.max(), 1e-30)
         assert np.abs(got - ref).max() <= tol, (k, np.abs(got - ref).max(), ref.max())
