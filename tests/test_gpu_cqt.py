@@ -85,3 +85,46 @@ def test_chroma_cqt_and_similarity(tmp_path):
     assert abs(s - ochroma.similarity(a16, b16)) < 2e-4
     assert similarity._calculate_similarity(str(tmp_path / "missing.wav"), b"", 44100, handle=h) == 0.0
     h.close()
+
+
+def test_chroma_follows_the_estimated_tuning():
+    """auto_matcher.py:68-69 leaves tuning=None: librosa estimates it and shifts the filter bank.  A clip played
+    20 cents sharp must be analysed with the shifted bank (same chroma as the oracle, different from the nominal grid)."""
+    from oracle import chroma as ochroma
+    from spectrogram_midi_amd import similarity
+    h = _lib.Handle()
+    t = np.arange(3 * 44100) / 44100
+    f = 261.6255653005986 * 2 ** (20 / 1200)
+    y = sum(a * np.sin(2 * np.pi * k * f * t) for k, a in ((1, 0.4), (2, 0.2), (4, 0.1))).astype(np.float32)
+    tn = similarity.estimate_tuning(y, 44100, 36)
+    assert tn == ochroma.estimate_tuning(y, 44100, bins_per_octave=36)
+    assert abs((tn - 0.6 + 0.5) % 1.0 - 0.5) <= 0.16            # 20 cents = 0.6 bin of a third of a semitone (wraps to -0.4)
+    got = similarity.chroma_cqt(h, [y])[0]
+    ref = ochroma.chroma_cqt(y)
+    assert np.abs(got - ref).max() < 2e-4
+    nominal = similarity.chroma_cqt(h, [y], tuning=0.0)[0]
+    assert np.abs(nominal - ochroma.chroma_cqt(y, tuning=0.0)).max() < 2e-4
+    assert np.abs(nominal - got).max() > 1e-2                       # the shift is visible in the chroma
+    h.close()
+
+
+def test_cqt_configs2_size_properties():
+    """BASELINE.json configs[2] at full size: 64 x 30 s polyphonic clips, 84 bins.  Size-independent properties:
+    a clip's result does not depend on the batch around it, magnitudes scale linearly with the gain, a delay of
+    whole hops shifts the frames, and spot checks against the float64 oracle on two clips."""
+    h = _lib.Handle()
+    base = [signals.polyphonic_clip(30.0, seed=100 + i) for i in range(4)]
+    rng = np.random.default_rng(3)
+    clips = [base[i % 4] if i < 4 else np.roll(base[i % 4], int(rng.integers(1, 10000))) for i in range(64)]
+    out = h.cqt(clips)
+    assert len(out) == 64 and all(o.shape == (84, 2584) for o in out)
+    np.testing.assert_array_equal(h.cqt([clips[5]])[0], out[5])                     # batch independence
+    half = h.cqt([np.float32(0.5) * clips[0]])[0]
+    np.testing.assert_allclose(half, 0.5 * out[0], rtol=2e-6, atol=1e-7 * out[0].max())   # linearity in the gain
+    delayed = h.cqt([np.concatenate([np.zeros(8 * 512, np.float32), clips[1]])])[0]
+    # interior frames (beyond the longest atom's half support, 11 686 samples = 23 frames) just move by 8 frames
+    np.testing.assert_allclose(delayed[:, 8 + 24:2584 - 24], out[1][:, 24:2584 - 8 - 24], rtol=0, atol=2e-5 * out[1].max())
+    ref = np.abs(ocqt.cqt(clips[2][:200 * 512], n_bins=84))
+    sub = h.cqt([clips[2][:200 * 512]])[0]
+    assert np.abs(sub - ref).max() <= 1e-4 * ref.max()
+    h.close()

@@ -179,3 +179,21 @@ def test_randomised_frame_arrays_match_oracle():
         events = eng.extract_events(raw, buf, **kw)
         assert same_events(events, ref_events), case
         assert buf.getvalue() == ref_blob, case
+
+
+def test_estimate_tuning_matches_oracle_and_known_answers():
+    """librosa.estimate_tuning as cqt(tuning=None) uses it (auto_matcher.py:68-69): the product's host routine and the
+    oracle's restatement agree exactly; a pure tone lands in the histogram cell of its deviation from the grid."""
+    from oracle import chroma as ochroma
+    from spectrogram_midi_amd import similarity
+    t = np.arange(2 * 44100) / 44100
+    for cents in (0, 7, -9, 14):
+        y = (0.5 * np.sin(2 * np.pi * 440.0 * 2 ** (cents / 1200) * t)).astype(np.float32)
+        tn = similarity.estimate_tuning(y, 44100, 36)
+        assert tn == ochroma.estimate_tuning(y, 44100, bins_per_octave=36)
+        want = cents / 100 * 3                              # bins of a third of a semitone
+        err = (tn - want + 0.5) % 1.0 - 0.5                 # circular: the estimate lives in [-0.5, 0.5)
+        # piptrack's parabolic interpolation of a Hann peak is a few cents off (librosa's behaviour, restated as is)
+        assert abs(err) <= 0.16, (cents, tn, want)
+    for y in (signals.guitar_clip(4.0, seed=5), signals.polyphonic_clip(4.0, seed=6), np.zeros(30000, np.float32)):
+        assert similarity.estimate_tuning(y, 44100, 36) == ochroma.estimate_tuning(y, 44100, bins_per_octave=36)
