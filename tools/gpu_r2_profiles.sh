@@ -1,0 +1,24 @@
+#!/bin/bash
+# round-2 profile set: everything lands in gpurun_out/r2prof/, the summaries judged are copied into profiles/ by hand
+set -o pipefail
+cd /root/repo
+O=/root/repo/gpurun_out/r2prof; mkdir -p $O
+export TMPDIR=/tmp
+timeout -k 10 300 python -m pytest tests/test_gpu_cqt.py tests/test_golden_v1_events.py tests/test_bench_launcher.py -m gpu -x -q > $O/newtests.log 2>&1; echo "new gpu tests rc=$?"; tail -3 $O/newtests.log
+timeout -k 10 300 python bench.py --steps 10 --warmup 3 > $O/bench_headline.json 2> $O/bench_headline.err; echo "headline rc=$?"; cut -c1-400 $O/bench_headline.json
+timeout -k 10 300 python bench.py --config cqt --steps 5 --warmup 2 > $O/bench_cqt.json 2> $O/bench_cqt.err; echo "cqt rc=$?"; cut -c1-1500 $O/bench_cqt.json
+timeout -k 10 400 python bench.py --config folder --steps 2 --warmup 1 --pass-frames 8400000 --no-cpu-baseline > $O/bench_folder.json 2> $O/bench_folder.err; echo "folder rc=$?"; cut -c1-300 $O/bench_folder.json
+timeout -k 10 300 python bench.py --clips 256 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_256.json 2> $O/bench_256.err; echo "256 rc=$?"; cut -c1-300 $O/bench_256.json
+cd /tmp
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o b -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1; echo "prof bench rc=$?"
+find /tmp/p_bench -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -o f -- python3 /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -o w -- python3 /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
+F=$(find /tmp/p_fetch -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_write -name "*counter_collection.csv" | head -1)
+python3 /root/repo/tools/summarize_pmc.py "$F" "$W" 2 $O/pmc_hbm.json > $O/pmc_summary.log 2>&1; echo "pmc summary rc=$?"; tail -30 $O/pmc_summary.log
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stream -o s -- python3 /root/repo/tools/bench_stream.py 1500 > $O/prof_stream.log 2>&1; echo "prof stream (graph) rc=$?"; grep -a "^{" $O/prof_stream.log | cut -c1-300
+find /tmp/p_stream -name "*kernel_stats.csv" -exec cp {} $O/stream_kernel_stats.csv \;
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trend -o t -- python3 /root/repo/tools/bench_trend.py > $O/prof_trend.log 2>&1; echo "prof trend rc=$?"; grep -a "^{" $O/prof_trend.log | cut -c1-600
+find /tmp/p_trend -name "*kernel_stats.csv" -exec cp {} $O/trend_kernel_stats.csv \;
+cd /root/repo; python3 tools/bench_stream.py 4000 > $O/stream_latency.json 2>&1; cat $O/stream_latency.json | cut -c1-300
+ls -la $O
