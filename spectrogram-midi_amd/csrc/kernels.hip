@@ -461,34 +461,52 @@ __device__ __forceinline__ int wave_min_i32(int v) {   // uniform result
     return __builtin_amdgcn_readlane(v, 63);
 }
 
-__global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb) {
-    // dynamic LDS: y[YN] (CMND, reused as the output row) | U | bfact[KM+1] | bexp[KM+1] | bcum[101], where U holds first
-    // the difference function dd[DN] and later, once the CMND is formed, the trough arrays th[KM], tp[KM], ti[KM], tbin[KM]
+// One frame per wave; a workgroup is up to 8 waves that share ONE copy of the scipy tables in LDS (16 waves per CU instead
+// of the 10 a private copy allowed) and walk `frames_per_wave` consecutive frames each.  The waves never exchange data: after
+// the table load the only synchronisation is inside a wave, where LDS operations complete in order.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(512) void pyin_obs_kernel(PassParams p, DevTables tb, int frames_per_wave) {
+    // dynamic LDS: bfact[KM+1] | bexp[KM+1] | bcum[101] (shared), then per wave y[YN] (CMND, reused as the output row) | U,
+    // where U holds first the difference function dd[DN] and later, once the CMND is formed, the trough arrays th[KM],
+    // tp[KM], ti[KM], tbin[KM]
     extern __shared__ __align__(16) unsigned char osm[];
     const int nl = p.n_lags, B = p.n_bins;
     const int KM = nl / 2 + 2;
     const int YN = (max(nl, B) + 1) & ~1;
     const int DN = (p.max_period + 1 + 24 + 1) & ~1;      // + look-ahead of the cumsum walk
-    const int UN = max(DN, 2 * KM + (5 * KM + 7) / 8);    // doubles
-    double *y = reinterpret_cast<double *>(osm);
+    const int UN = max(DN, 2 * KM + (4 * KM + 7) / 8);    // doubles
+    const int TN = (2 * (KM + 1) + 101 + 1) & ~1;
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
+    double *bfact = reinterpret_cast<double *>(osm);      // scipy.stats.boltzmann pieces and the Beta mass prefix sums: every lookup
+    double *bexp = bfact + (KM + 1);                      // below is data dependent, so they sit in LDS instead of behind a global
+    double *bcum = bexp + (KM + 1);                       // load each
+    double *y = bfact + TN + (size_t)wid * (YN + UN);
     double *row = y;                       // written only after the last read of y
     double *dd = y + YN;
     double *th = dd;
     double *tp = th + KM;
     int16_t *ti = reinterpret_cast<int16_t *>(tp + KM);
     int16_t *tbin = ti + KM;
-    double *bfact = dd + UN;               // scipy.stats.boltzmann pieces and the Beta mass prefix sums: every lookup below
-    double *bexp = bfact + (KM + 1);       // is data dependent, so they sit in LDS instead of behind a global load each
-    double *bcum = bexp + (KM + 1);
     __shared__ double beta_s[104];
 
-    const int lane = threadIdx.x;
-    if ((int64_t)blockIdx.x >= geo_n_sel(p)) return;
+    for (int i = threadIdx.x; i < 100; i += blockDim.x) beta_s[i] = tb.beta_probs[i];
+    for (int i = threadIdx.x; i <= KM; i += blockDim.x) { bfact[i] = tb.boltz_fact[i]; bexp[i] = tb.boltz_exp[i]; }
+    for (int i = threadIdx.x; i <= 100; i += blockDim.x) bcum[i] = tb.beta_cumsum[i];
+    __syncthreads();
+
+    for (int it = 0; it < frames_per_wave; ++it) {
+    const int64_t fsel = ((int64_t)blockIdx.x * nwaves + wid) * frames_per_wave + it;
+    if (fsel >= geo_n_sel(p)) break;                      // wave-uniform
     int64_t f, fo;
     {
         int c;
         int64_t t;
-        map_frame(p, (int64_t)blockIdx.x, c, t, f);
+        map_frame(p, fsel, c, t, f);
         fo = out_index(p, c, t);
     }
     // Cumulative-mean-normalised difference (pitch.py::_cumulative_mean_normalized_difference) from the difference
@@ -497,11 +515,9 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     // all lanes.  The CMND itself never leaves the CU.
     const int mp = p.max_period, minp = p.min_period;
     const double *__restrict__ dr = p.dfn + f * (int64_t)p.lag_stride;
+    wave_sync();                            // the previous frame's output row has been read out of this wave's buffers
     for (int i = lane; i <= mp; i += 64) dd[i] = dr[i];
-    for (int i = lane; i < 100; i += 64) beta_s[i] = tb.beta_probs[i];
-    for (int i = lane; i <= KM; i += 64) { bfact[i] = tb.boltz_fact[i]; bexp[i] = tb.boltz_exp[i]; }
-    for (int i = lane; i <= 100; i += 64) bcum[i] = tb.beta_cumsum[i];
-    __syncthreads();
+    wave_sync();
     if (lane == 0) {
         // Straight-line blocks of 8 lags, the next block's values fetched while the current block's dependent adds
         // run: the walk is bound by the add latency, not by an LDS round trip (or a branch) per lag.  dd is padded,
@@ -534,17 +550,17 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         }
         for (; tau <= mp; ++tau) { cs = cs + dd[tau]; y[tau - minp] = cs; }
     }
-    __syncthreads();
+    wave_sync();
     for (int i = lane; i < nl; i += 64) {
         const int tau = i + minp;
         y[i] = dd[tau] / (y[i] / (double)tau + DBL_MIN);
     }
     if (p.yin != nullptr) {                 // stage-level parity tests only (AEGIS_DEBUG_STAGES=1)
-        __syncthreads();
+        wave_sync();
         double *__restrict__ yo = p.yin + f * (int64_t)p.yin_stride;
         for (int i = lane; i < nl; i += 64) yo[i] = y[i];
     }
-    __syncthreads();
+    wave_sync();
 
     // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
     const int CH = (nl + 63) >> 6;
@@ -568,7 +584,7 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         for (int r = 0; r < CH; ++r)
             if (mask & (1u << r)) { const int i = lane * CH + r; th[k] = y[i]; ti[k] = (int16_t)i; ++k; }
     }
-    __syncthreads();
+    wave_sync();
 
     double vp = 0.0;
     const int rounds = (K + 63) >> 6;
@@ -693,9 +709,9 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
                 }
             }
         }
-        __syncthreads();                 // last read of y is behind us: the buffer becomes the output row
+        wave_sync();                 // last read of y is behind us: the buffer becomes the output row
         for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
-        __syncthreads();
+        wave_sync();
         if (K > 0) {
             // observation_probs[bin, t] = probs: on duplicate bins the largest lag wins; bins are
             // non-increasing in lag, so a trough loses exactly when the next trough with
@@ -740,7 +756,7 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
     };
     if (rounds <= 2) tail(std::integral_constant<int, 2>{});
     else tail(std::integral_constant<int, kMaxRounds>{});
-    __syncthreads();
+    wave_sync();
     double *__restrict__ orow = p.logobs + f * (int64_t)p.obs_stride;
     for (int b = lane; b < B; b += 64) orow[b] = row[b];
     if (lane == 0) {
@@ -748,6 +764,7 @@ __global__ __launch_bounds__(64) void pyin_obs_kernel(PassParams p, DevTables tb
         p.logunv[f] = log(unv + DBL_MIN);
         if (p.out_vprob != nullptr) p.out_vprob[fo] = vp;
     }
+    }   // frames of this wave
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1616,6 +1633,9 @@ hipError_t viterbi_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(frame_yin_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(pyin_obs_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);       // + 832 B static
+    if (e != hipSuccess) return e;
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
@@ -1642,11 +1662,16 @@ void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0) return;
     const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1, DN = (p.max_period + 1 + 24 + 1) & ~1;
-    const int UN = std::max(DN, 2 * KM + (5 * KM + 7) / 8);
-    const size_t lds = (size_t)(YN + UN + 2 * (KM + 1) + 101) * 8 + 16;
-    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)p.n_sel), dim3(64), lds, s, p, t);
+    const int UN = std::max(DN, 2 * KM + (4 * KM + 7) / 8), TN = (2 * (KM + 1) + 101 + 1) & ~1;
+    // eight waves share one copy of the tables (two such workgroups per CU); small launches (streaming pushes) get a wave
+    // per frame and one frame per wave
+    int waves = (int)std::min<int64_t>(8, p.n_sel);
+    while (waves > 1 && (size_t)(TN + waves * (YN + UN)) * 8 + 1024 > 80 * 1024) --waves;
+    const int fpw = p.n_sel >= 4096 ? 4 : 1;
+    const size_t lds = (size_t)(TN + waves * (YN + UN)) * 8;
+    const int64_t per_wg = (int64_t)waves * fpw;
+    hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)((p.n_sel + per_wg - 1) / per_wg)), dim3(64 * waves), lds, s, p, t, fpw);
 }
-// The Viterbi recurrence is latency-bound on its one CU per clip: any other wave on that CU takes issue slots from it.
 // AEGIS_VITERBI_EXCLUSIVE=<clips> (experiment knob, default off): launches of up to that many clips ask for the whole 160 KB
 // of LDS, so that no frame-stage workgroup can be placed on the same CU.  Measured: no gain (64 clips: 83.6 vs 78.9 ms) --
 // what slows the Viterbi is frame-stage code on the NEIGHBOURING CU (shared instruction cache), which the CU-partitioned
