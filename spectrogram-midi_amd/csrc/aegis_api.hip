@@ -48,11 +48,14 @@ struct aegis_handle {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
+    int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
+    int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
     // CU-partitioned stream sets of the pipeline (split_streams): [0] Viterbi on 64 CUs / frame stage on 192, [1] 128 / 128
     struct SplitSet { hipStream_t frame_a = nullptr, frame_b = nullptr, viterbi = nullptr; bool tried = false; } split[2];
+    int n_cus = 0;                            // compute units of the device (CU masks are built for this count)
     int split_limit = 64;                     // passes of up to this many clips run partitioned (AEGIS_CU_SPLIT=0 disables)
     hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
@@ -263,7 +266,11 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
         if (v >= 64 && v % kViterbiChunk == 0) h->time_chunk = v;
     }
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
+    if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
+    if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
+    if (const char *e = std::getenv("AEGIS_RAMP_K")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 64) h->ramp_k = (int)v; }
     if (const char *e = std::getenv("AEGIS_CU_SPLIT")) h->split_limit = std::atoi(e);
+    CRTHIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, c.device));
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
     CRT(ensure(h, h->vstats, 16));
@@ -402,6 +409,7 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
 // therefore runs on CU-masked streams: the Viterbi on the last V CUs of the mask, the frame stage on the others.
 static aegis_handle::SplitSet *split_streams(aegis_handle *h, int n_clips) {
     if (n_clips > h->split_limit || h->split_limit <= 0) return nullptr;
+    if (h->n_cus != 256) return nullptr;      // the masks below are laid out for the 256 CUs of an un-partitioned MI355X
     // 65..128 clips: a 128 / 128 partition starves the frame stage (170.8 vs 120.9 ms at 128 clips); only reachable
     // through AEGIS_CU_SPLIT
     const int idx = n_clips <= 64 ? 0 : 1;
@@ -516,10 +524,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         const int64_t kTimeChunk = h->time_chunk;      // multiple of kViterbiChunk
         std::vector<int64_t> cb{0};
         if (py && maxF > kTimeChunk + kTimeChunk / 2) {
-            int64_t step = std::max<int64_t>(kViterbiChunk, kTimeChunk / 4 / kViterbiChunk * kViterbiChunk);
+            int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
             while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
-                step = std::min<int64_t>(kTimeChunk, (step * 5 / 4 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                step = std::min<int64_t>(kTimeChunk, (step * h->chunk_growth_pct / 100 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
                 cb.push_back(cb.back() + step);
             }
         }
@@ -546,7 +554,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
         // first four (short) chunks, whose kernels are too small to fill the chip on their own.
         const bool two_fs = py && nk > 2 && nc >= 128;
-        const int ramp_k = (py && nk > 2 && !two_fs) ? 4 : 0;
+        const int ramp_k = (py && nk > 2 && !two_fs) ? h->ramp_k : 0;
         const bool use_fb = two_fs || ramp_k > 0;
         while ((int)h->sync_events.size() < EV_CHUNK0 + nk) {
             hipEvent_t e;

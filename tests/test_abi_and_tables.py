@@ -147,10 +147,10 @@ def test_product_does_not_import_oracle():
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    """profiles/r1_e_bench.json is bench.py's own output on the MI355X: metric / value / n_gpus / steps / warmup /
+    """profiles/r2_bench.json is bench.py's own output on the MI355X: metric / value / n_gpus / steps / warmup /
     ms_per_step / scaling / dtype / data / config.workload plus the roofline and cpu_baseline objects."""
     import json, os
-    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r1_e_bench.json")
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r2_bench.json")
     d = json.load(open(p))
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -159,9 +159,12 @@ def test_committed_bench_line_has_the_contract_fields():
     r = d["roofline"]
     assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-5 and r["unit"] == "GB/s"
     assert r["traffic"] is None or r["traffic"] > 0
+    assert "traffic_static" in r and 0 < r["cus_busy_fraction"] <= 1
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert c["turbo"]["cores"] >= 1 and c["turbo"]["value"] > 0           # the reference's Turbo Mode beside the stable path
     assert abs(d["value"] - 64 * 180 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-3
+    assert len(d["rank_busy_ms"]) == d["n_gpus"] and "events" in d
 
 
 def _build_c_demo(tmp_path):
