@@ -99,19 +99,20 @@ __host__ __device__ inline int frame_en_stride(int max_period) {
 //   C  j = 1024 + tau     row[tau] = e[1024 + tau] - e[tau]
 // `fetch(j0, a, b)` returns samples j0..j0+7 of the lane's frame; the next block is requested before the current
 // block's eight dependent adds.  The row is over-written in whole blocks (entries past max_period are never read).
-template <typename Fetch>
+template <bool SQUARED, typename Fetch>
 __device__ __forceinline__ void energy_walk(Fetch fetch, float *__restrict__ row, int mp) {
     const int nA = (mp + 8) >> 3;
     float4 a, b, na, nb;
     fetch(0, a, b);
     float e = 0.0f;                 // 0 + x*x == x*x exactly: the first add reproduces np.cumsum's first element
     int j0 = 0;
-#define AEGIS_CHAIN8(ea, eb)                                                             \
-    { float sq;                                                                          \
-      sq = a.x * a.x; e = e + sq; ea.x = e;  sq = a.y * a.y; e = e + sq; ea.y = e;       \
-      sq = a.z * a.z; e = e + sq; ea.z = e;  sq = a.w * a.w; e = e + sq; ea.w = e;       \
-      sq = b.x * b.x; e = e + sq; eb.x = e;  sq = b.y * b.y; e = e + sq; eb.y = e;       \
-      sq = b.z * b.z; e = e + sq; eb.z = e;  sq = b.w * b.w; e = e + sq; eb.w = e; }
+#define AEGIS_SQ(x) (SQUARED ? (x) : (x) * (x))
+#define AEGIS_CHAIN8(ea, eb)                                                                     \
+    { float sq;                                                                                  \
+      sq = AEGIS_SQ(a.x); e = e + sq; ea.x = e;  sq = AEGIS_SQ(a.y); e = e + sq; ea.y = e;       \
+      sq = AEGIS_SQ(a.z); e = e + sq; ea.z = e;  sq = AEGIS_SQ(a.w); e = e + sq; ea.w = e;       \
+      sq = AEGIS_SQ(b.x); e = e + sq; eb.x = e;  sq = AEGIS_SQ(b.y); e = e + sq; eb.y = e;       \
+      sq = AEGIS_SQ(b.z); e = e + sq; eb.z = e;  sq = AEGIS_SQ(b.w); e = e + sq; eb.w = e; }
     for (int k = 0; k < nA; ++k, j0 += 8) {
         fetch(j0 + 8, na, nb);
         float4 ea, eb;
@@ -137,6 +138,7 @@ __device__ __forceinline__ void energy_walk(Fetch fetch, float *__restrict__ row
         a = na; b = nb;
     }
 #undef AEGIS_CHAIN8
+#undef AEGIS_SQ
 }
 constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1040 * 4 + 128 * 4 + 16 * 4 + 256 * 4;
 
@@ -215,7 +217,8 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         if (staged) {                                // sample i sits at i + 4 (i / 512): the lanes' frames start one hop apart,
             for (int i = tid; i < (int)span; i += 256) {     // the skew puts their 16-byte reads on distinct bank groups
                 const int64_t idx = g0.start + i;
-                stage[i + 4 * (i >> 9)] = (idx >= 0 && idx < g0.n) ? p.pcm[g0.base + idx] : 0.0f;
+                const float v = (idx >= 0 && idx < g0.n) ? p.pcm[g0.base + idx] : 0.0f;
+                stage[i + 4 * (i >> 9)] = v * v;              // squared here, by all threads, not inside the serial walk
             }
             __syncthreads();
         }
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             float *row = en + lane * en_stride;
             if (staged) {
                 const float *srow = stage + lane * (512 + 4);
-                energy_walk([&](int j, float4 &a, float4 &b) {
+                energy_walk<true>([&](int j, float4 &a, float4 &b) {
                     const float *q = srow + j + 4 * (j >> 9);                // j + 8 <= 1024 + 8 nA + 8 < 2048: inside the frame
                     a = *reinterpret_cast<const float4 *>(q);
                     b = *reinterpret_cast<const float4 *>(q + 4);
@@ -231,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             } else {                                         // frames of two clips, or a hop the staging area cannot hold
                 const Geo g = locate(lane);
                 const float *__restrict__ x = p.pcm + g.base;
-                energy_walk([&](int j, float4 &a, float4 &b) {
+                energy_walk<false>([&](int j, float4 &a, float4 &b) {
                     float v[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) { const int64_t q = g.start + j + i; v[i] = (q >= 0 && q < g.n) ? x[q] : 0.0f; }
