@@ -193,7 +193,7 @@ class Handle:
 
     def viterbi_stats(self, reset=True):
         """{"wave_steps", "list_only"}: voiced-source evaluations of the band Viterbi since the last reset and how many
-        of them took the exact observed-sources-only path (kernels.hip); None on a host-only handle."""
+        of them took the exact observed-sources-only path (viterbi.hip); None on a host-only handle."""
         if self.device < 0:
             return None
         v = np.zeros(2, np.int64)

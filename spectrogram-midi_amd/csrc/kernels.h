@@ -24,7 +24,7 @@ struct DevTables {
     const double *boltz_fact;  // [n]
     const double *boltz_exp;   // [n]
     const double *lt_band;     // [4][n_cls][width]
-    const double *lt_pack;     // [2 (stay, switch)][3H^2+3H+2] packed band table (kernels.hip pk_*), or nullptr
+    const double *lt_pack;     // [2 (stay, switch)][3H^2+3H+2] packed band table (viterbi.hip pk_*), or nullptr
     const double *freqs;       // [n_bins]
     const double2 *twiddle;    // [2048]
 };
@@ -104,6 +104,7 @@ void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *
                           hipStream_t s);
 hipError_t frame_debug_fetch(long long *dst);                // frame_yin_kernel section cycles (AEGIS_ABLATE&128)
 hipError_t viterbi_debug_fetch(long long *dst, bool reset);   // per-wave section cycles (zeros unless AEGIS_ABLATE&64)
-hipError_t viterbi_configure();   // raises the dynamic-LDS limit once
+hipError_t viterbi_configure();   // raises the dynamic-LDS limits once (all kernels)
+hipError_t viterbi_set_lds_limits();   // viterbi.hip's share of it
 
 }  // namespace aegis

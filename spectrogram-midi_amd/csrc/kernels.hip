@@ -2,11 +2,10 @@
 //
 // Reference behaviour being reproduced (the arithmetic lives in librosa, which
 // /root/reference/aegis_engine.py:25-26,63,67,70 calls):
-//   frame_fft_kernel   melspectrogram power + feature.rms + the FFT autocorrelation
-//                      of pyin's difference function          
-//   yin_seq_kernel     running energy, difference, CMND        (P3, P4)
-//   pyin_obs_kernel    troughs, threshold prior, pitch-bin observation (P5-P10)
-//   viterbi_kernel     882-state log-Viterbi with chunked back-tracking (P11, P12)
+//   frame_yin_kernel   melspectrogram power + feature.rms + pyin's difference function
+//                      (FFT autocorrelation + running energy)  
+//   pyin_obs_kernel    CMND, troughs, threshold prior, pitch-bin observation (P4-P10)
+//   (viterbi.hip)      882-state log-Viterbi with chunked back-tracking (P11, P12)
 //   finalize kernels   power_to_db(ref=max), rake mask (vision.py:3-38), f0 decode
 //
 // Built with -ffp-contract=off: every multiply/add below rounds exactly where
@@ -771,671 +770,6 @@ __global__ __launch_bounds__(512) void pyin_obs_kernel(PassParams p, DevTables t
 }
 
 // ------------------------------------------------------------------------------------------
-// Kernel 4: log-domain Viterbi, one workgroup per clip, one thread per HMM state.
-//
-// librosa's transition matrix is kron(loop(2, .99), local(B, width)) + tiny, dense.  A target
-// state (v', b') therefore sees 2*width in-band predecessors with distinct log-probabilities
-// and every other state at log(tiny).  Among those out-of-band predecessors only the global
-// arg-max of the previous column can win (any in-band candidate built on that arg-max beats
-// log(tiny)), so each step evaluates the band exactly and one extra candidate.  arg-max ties
-// resolve to the lowest state index, as np.argmax does.
-//
-// Back-pointers go to HBM; every kViterbiChunk steps the chunk's pointer maps are composed in
-// LDS into one map per chunk, so the final back-trace is a short serial walk over chunk maps
-// followed by a parallel walk inside the chunks.
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables tb, int lt_in_lds) {
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int B = p.n_bins, S = 2 * B, H = p.half_width, W = p.width, NC = p.n_cls;
-    const int SP = (S + 63) & ~63;
-    constexpr int C = kViterbiChunk;
-    double *val = reinterpret_cast<double *>(smem_raw);   // [2][SP]
-    double *rv = val + 2 * SP;                            // [2][16]
-    int *ri = reinterpret_cast<int *>(rv + 32);           // [2][16]
-    uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [C][S]
-    double *ltl = reinterpret_cast<double *>(smem_raw + ((2 * SP + 32) * 8 + 32 * 4 + C * S * 2 + 15) / 16 * 16);
-
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
-    if (lt_in_lds)
-        for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = tb.lt_band[i];
-    const double *lt = lt_in_lds ? ltl : tb.lt_band;
-
-    const int c = p.order[blockIdx.x];
-    const int64_t f0 = p.frame_off[c];
-    const int T = (int)(p.frame_off[c + 1] - f0);
-    const int os = p.obs_stride;
-    const double *__restrict__ lobs = p.logobs + f0 * os;
-    const double *__restrict__ lunv = p.logunv + f0;
-    uint16_t *__restrict__ ptr = p.ptr + f0 * S;
-    const int64_t ch0 = p.chunk_off[c];
-    uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
-    int32_t *__restrict__ bnd = p.bnd + ch0;
-    int32_t *__restrict__ states = p.states + f0;
-    const int nch = (T - 1 + C - 1) / C;
-
-    const int j = tid;
-    const bool act = j < S;
-    const int v2 = (j >= B) ? 1 : 0;
-    const int b2 = j - v2 * B;
-    const int dlo = max(0, H - b2);
-    const int dhi = min(W - 1, B - 1 - b2 + H);
-
-    const int64_t vt_begin = geo_vt_begin(p), vt_end = geo_vt_end(p);
-    if (p.ctl && p.ctl->n_sel == 0) return;                     // graph replay of a push that completed no frame
-    const int t_lo = (int)(vt_begin > 1 ? vt_begin : 1);
-    const int t_hi = (int)(vt_end < T ? vt_end : T);
-    if (vt_begin >= T && vt_begin != 0) return;                 // clip finished in an earlier launch
-    double *__restrict__ vst = p.vstate + (int64_t)c * S;
-    double myv = -INFINITY;
-    if (act) {
-        if (vt_begin == 0) {
-            const double lp = v2 ? lunv[0] : lobs[b2];
-            myv = lp + p.log_pinit;
-        } else {
-            myv = vst[j];
-        }
-        val[j] = myv;
-    }
-    int par = 0;
-    double G;
-    int kg;
-    auto block_argmax = [&](double v, int ix) {
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) {
-            const double ov = __shfl_down(v, o);
-            const int oi = __shfl_down(ix, o);
-            if (ov > v || (ov == v && oi < ix)) { v = ov; ix = oi; }
-        }
-        if (lane == 0) { rv[par * 16 + wid] = v; ri[par * 16 + wid] = ix; }
-        __syncthreads();
-        G = rv[par * 16]; kg = ri[par * 16];
-        for (int w = 1; w < nw; ++w) {
-            const double ov = rv[par * 16 + w];
-            const int oi = ri[par * 16 + w];
-            if (ov > G || (ov == G && oi < kg)) { G = ov; kg = oi; }
-        }
-        par ^= 1;
-    };
-    block_argmax(myv, act ? j : 0x7fffffff);
-    if (p.live_states != nullptr && tid == 0 && vt_begin == 0) p.live_states[f0] = kg;
-
-    double *cur = val, *nxt = val + SP;
-    for (int t = t_lo; t < t_hi; ++t) {
-        double lp = 0.0;
-        if (act) lp = v2 ? lunv[t] : lobs[(int64_t)t * os + b2];
-        double best = -INFINITY;
-        int bi = 0;
-        if (act) {
-#pragma unroll
-            for (int v = 0; v < 2; ++v) {
-                const double *cv = cur + v * B;
-                const double *ltv = lt + (size_t)(v * 2 + v2) * NC * W;
-                for (int d = dlo; d <= dhi; ++d) {
-                    const int b = b2 + d - H;
-                    const int cl = b < H ? b : (b > B - 1 - H ? b - (B - 1 - 2 * H) : H);
-                    const double cand = cv[b] + ltv[cl * W + (W - 1 - d)];
-                    if (cand > best) { best = cand; bi = v * B + b; }
-                }
-            }
-            const int bg = kg >= B ? kg - B : kg;
-            const int dist = bg > b2 ? bg - b2 : b2 - bg;
-            if (dist > H) {
-                const double cand = G + p.log_tiny;
-                if (cand > best || (cand == best && kg < bi)) { best = cand; bi = kg; }
-            }
-            myv = lp + best;
-            nxt[j] = myv;
-            ring[((t - 1) % C) * S + j] = (uint16_t)bi;
-            ptr[(int64_t)t * S + j] = (uint16_t)bi;
-        }
-        block_argmax(myv, act ? j : 0x7fffffff);
-        if (p.live_states != nullptr && tid == 0) p.live_states[f0 + t] = kg;
-        double *tmp = cur; cur = nxt; nxt = tmp;
-        if (t % C == 0 || t == T - 1) {
-            const int cc = (t - 1) / C;
-            if (act) {
-                int s = j;
-                for (int tt = t; tt > cc * C; --tt)      // steps of an earlier launch (streaming): pointers from HBM
-                    s = tt >= t_lo ? ring[((tt - 1) % C) * S + s] : ptr[(int64_t)tt * S + s];
-                cmap[(int64_t)cc * S + j] = (uint16_t)s;
-            }
-            __syncthreads();
-        }
-    }
-
-    if (t_hi < T) {                       // more launches follow: hand the column over
-        if (act) vst[j] = myv;
-        return;
-    }
-    // back-trace: serial over chunk maps, then parallel inside the chunks
-    if (tid == 0) {
-        int s = kg;
-        for (int cc = nch - 1; cc >= 0; --cc) { bnd[cc] = s; s = cmap[(int64_t)cc * S + s]; }
-        states[0] = s;
-    }
-    __threadfence();
-    __syncthreads();
-    for (int cc = tid; cc < nch; cc += nthr) {
-        const int te = min((cc + 1) * C, T - 1);
-        int s = bnd[cc];
-        states[te] = s;
-        for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// Kernel 4 (band-specialised): the same recurrence with the half width H known at compile
-// time.  Thread layout: two voicing halves of BP = roundup(B, 64) threads, so the target's
-// voicing v' is wave-uniform.  Sources are split by the class of their transition row:
-//   * interior rows (H <= b <= B-1-H) all share one 4 x (2H+1) table: the values live in a
-//     -inf padded LDS array, the 2(2H+1) candidates are a fully unrolled loop of
-//     ds_read_b64 (immediate offset) + v_add_f64 with a scalar table operand + compare/select;
-//   * edge rows (b < H or b > B-1-H) are row-normalised differently: only waves within reach
-//     of an edge walk them, one source at a time (source uniform, table lookup per lane).
-// Candidate order does not matter for the result: ties are resolved explicitly to the lowest
-// state index wherever the evaluation order is not the index order.
-// ------------------------------------------------------------------------------------------
-// wave64 max of a double via DPP row shifts / row broadcasts (result valid in lane 63)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_fmax(double v) {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
-    const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
-    return fmax(v, __hiloint2double(hi2, lo2));
-}
-__device__ __forceinline__ double row16_prefix_max(double v) {   // lane 15 of each row = row max
-    v = dpp_fmax<0x111, 0xf>(v);   // row_shr:1
-    v = dpp_fmax<0x112, 0xf>(v);   // row_shr:2
-    v = dpp_fmax<0x114, 0xf>(v);   // row_shr:4
-    v = dpp_fmax<0x118, 0xf>(v);   // row_shr:8
-    return v;
-}
-__device__ __forceinline__ double read_lane_f64(double v, int l) {
-    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l),
-                            __builtin_amdgcn_readlane(__double2loint(v), l));
-}
-
-// Interior-row log-transition table, passed BY VALUE: kernel arguments live in the kernarg
-// segment, which the compiler reads with scalar loads (s_load_dwordx16) -- the 2(2H+1) table
-// operands of a step then sit in SGPRs and cost no vector memory traffic or VGPRs.
-// Packed band table kept in LDS: the four (v,v') blocks of log(kron(loop, local) + tiny) are only two distinct ones
-// (loop is symmetric: "stay" = v == v', "switch"), and an edge row only reaches the targets that exist, so a block
-// is [sentinel][low-edge rows e = 0..H-1: dd = H-e..2H][interior row: dd = 0..2H][high-edge rows e = 0..H-1:
-// dd = 0..2H-1-e] = 3H^2 + 3H + 2 entries (15.6 KB at H = 25, 61 KB at H = 50 -- the full [4][2H+1][2H+1] table of
-// the 22.05 kHz band would be 326 KB).
-template <int H> __host__ __device__ constexpr int pk_lo_start(int e) { return 1 + e * (H + 1) + e * (e - 1) / 2; }
-template <int H> __host__ __device__ constexpr int pk_int_start() { return 1 + H * (H + 1) + H * (H - 1) / 2; }
-template <int H> __host__ __device__ constexpr int pk_hi_start(int e) { return pk_int_start<H>() + (2 * H + 1) + 2 * H * e - e * (e - 1) / 2; }
-template <int H> __host__ __device__ constexpr int pk_size() { return 3 * H * H + 3 * H + 2; }
-// The packed layout costs a few scalar multiplies per list entry but 50 KB of LDS instead of 102 at H = 25, which lets a
-// frame-stage workgroup share the CU when the batch fills the chip (256 clips: 240 -> 226 ms); measured neutral at 64 clips.
-__host__ __device__ constexpr bool band_table_packed(int) { return true; }
-
-template <int H>
-struct BandLT {
-    double v[4][2 * H + 1];   // [v*2+v'][dd]
-    double lmax[4];           // [v*2+v'] largest log-transition of that block over ALL row classes
-    double lmax_all;          // largest log-transition of the whole matrix
-};
-
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
-__device__ long long g_vit_dbg[16 * 8];
-#define VIT_TICK(k) { const long long now__ = clock64(); tacc[k] += now__ - tlast; tlast = now__; }
-#else
-#define VIT_TICK(k)
-#endif
-
-template <int H, bool LT_LDS>
-__global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTables tb, BandLT<H> blt) {
-    constexpr int W = 2 * H + 1;
-    constexpr int C = kViterbiChunk;
-    extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int B = p.n_bins, S = 2 * B, NC = p.n_cls;
-    const int BP = (B + 63) & ~63;
-    const int PADB = (B + 2 * H + 64 + 7) & ~7;            // slack: inactive lanes read past B+2H
-    double *valI = reinterpret_cast<double *>(smem_raw);   // [2 buf][2 v][PADB], index b + H
-    double *valE = valI + 4 * PADB;                        // [2 buf][2 v][2H]
-    double *rv = valE + 8 * H;                             // [2][16]  wave maxima
-    double *vobs = rv + 32;                                // [2][16]  largest value among a voiced wave's observed states
-    unsigned long long *omask = reinterpret_cast<unsigned long long *>(rv + 64);   // [2][16] observed-state ballots of the voiced waves
-    int *ri = reinterpret_cast<int *>(omask + 32);         // [2][16]
-    uint16_t *ring = reinterpret_cast<uint16_t *>(ri + 32);   // [2][S] chunk-origin maps
-    double *ltl = reinterpret_cast<double *>(
-        smem_raw + (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)2 * S * 2 + 15) / 16) * 16);   // [2][NP]
-    constexpr int NP = pk_size<H>();
-    // The packed layout costs a few scalar multiplies per list entry (row starts are quadratic in the class); the
-    // 44.1 kHz band (H = 25) keeps the full table, whose 83 KB fit; the 22.05 kHz band (H = 50) needs the packing.
-    constexpr bool PK = LT_LDS && band_table_packed(H);
-
-    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wid = tid >> 6, nw = nthr >> 6;
-    const int vp = __builtin_amdgcn_readfirstlane(tid >= BP ? 1 : 0);
-    const int b2 = tid - vp * BP;
-    const bool act = b2 < B;
-    const int b2c = act ? b2 : 0;
-    const int j = vp * B + b2c;
-    const int wlo = __builtin_amdgcn_readfirstlane(b2 - lane), whi = wlo + 63;
-    const bool wave_low = wlo < 2 * H;            // some target of this wave sees low-edge sources
-    const bool wave_high = whi >= B - 2 * H;      // ... high-edge sources (never both: B >= 4H+128)
-    const bool is_low = b2c < H, is_high = b2c > B - 1 - H;
-    const int eidx = is_low ? b2c : b2c - B + 2 * H;
-
-    // Issue priority by expected work: the step ends when the slowest wave reaches the barrier, and the SIMD arbiter
-    // otherwise serves the oldest wave first.  Edge waves (25 or 50 extra candidates per source voicing) first, then
-    // the low-bin waves (most observed sources: sub-harmonic troughs crowd the low bins), then the rest
-    // (a separate, lower level for the voiced-target interior waves starved them: +2 %); measured 76.3 -> 72.5 ms
-    // when introduced.  Priorities by list length per step cost more than they gain.
-    if (wave_low || wave_high) __builtin_amdgcn_s_setprio(3);
-    else if (wlo < 128) __builtin_amdgcn_s_setprio(2);
-    else __builtin_amdgcn_s_setprio(1);
-    for (int i = tid; i < 4 * PADB + 8 * H; i += nthr) valI[i] = -INFINITY;
-    // LDS copy of the band table (edge rows + list lookups).  Slot [class 0][dd = 0] of every (v,v')
-    // block is never a real transition (it would be a target bin of -H): it holds the -inf sentinel
-    // that out-of-reach (lane, source) pairs are redirected to.
-    // Slot 0 of each packed block holds the -inf sentinel that out-of-reach (lane, source) pairs are redirected to.
-    const double *lt_e0, *lt_e1;   // blocks (v = 0 -> v' = vp) and (v = 1 -> v' = vp)
-    if (PK) {
-        for (int i = tid; i < 2 * NP; i += nthr) ltl[i] = (i % NP == 0) ? -INFINITY : tb.lt_pack[i];
-        lt_e0 = ltl + (vp ? NP : 0);            // "stay" block first, "switch" block second
-        lt_e1 = ltl + (vp ? 0 : NP);
-    } else if (LT_LDS) {
-        // full table; slot [class 0][dd = 0] of every block is never a real transition (target bin -H): sentinel
-        for (int i = tid; i < 4 * NC * W; i += nthr) ltl[i] = (i % (NC * W) == 0) ? -INFINITY : tb.lt_band[i];
-        lt_e0 = ltl + (size_t)vp * NC * W;
-        lt_e1 = lt_e0 + (size_t)2 * NC * W;
-    } else {
-        lt_e0 = tb.lt_band + (size_t)vp * NC * W;
-        lt_e1 = lt_e0 + (size_t)2 * NC * W;
-    }
-    const double *lti0 = blt.v[0 * 2 + vp];   // interior row, source v = 0, target v' = vp
-    const double *lti1 = blt.v[1 * 2 + vp];   // source v = 1
-    constexpr int kSentinel = 0;
-
-    const int c = p.order[blockIdx.x];
-    const int64_t f0 = p.frame_off[c];
-    const int T = (int)(p.frame_off[c + 1] - f0);
-    const int os = p.obs_stride;
-    const double *__restrict__ lobs = p.logobs + f0 * os;
-    const double *__restrict__ lunv = p.logunv + f0;
-    uint16_t *__restrict__ ptr = p.ptr + f0 * S;
-    const int64_t ch0 = p.chunk_off[c];
-    uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
-    int32_t *__restrict__ bnd = p.bnd + ch0;
-    int32_t *__restrict__ states = p.states + f0;
-    const int nch = (T - 1 + C - 1) / C;
-    __syncthreads();
-
-    auto store_value = [&](int buf, double v) {
-        if (is_low || is_high) valE[(buf * 2 + vp) * 2 * H + eidx] = v;
-        else valI[(buf * 2 + vp) * PADB + b2c + H] = v;
-    };
-
-    const int64_t vt_begin = geo_vt_begin(p), vt_end = geo_vt_end(p);
-    if (p.ctl && p.ctl->n_sel == 0) return;                     // graph replay of a push that completed no frame
-    const int t_lo = (int)(vt_begin > 1 ? vt_begin : 1);
-    const int t_hi = (int)(vt_end < T ? vt_end : T);
-    if (vt_begin >= T && vt_begin != 0) return;                 // clip finished in an earlier launch
-    double *__restrict__ vst = p.vstate + (int64_t)c * S;
-    double myv = -INFINITY;
-    bool observed = false;        // voiced state whose observation at the column's frame is not log(tiny)
-    if (act) {
-        const int tprev = vt_begin == 0 ? 0 : t_lo - 1;
-        const double lp = vp ? lunv[tprev] : lobs[(int64_t)tprev * os + b2c];
-        myv = vt_begin == 0 ? lp + p.log_pinit : vst[j];
-        observed = !vp && lp != p.log_tiny;
-        store_value(0, myv);
-    }
-    // Back-pointer chunk maps are composed on the fly: org[s] = state at the start of the current 16-step chunk
-    // of the best path into s (one dependent LDS gather per step, double buffered), stored as the chunk map when
-    // the chunk closes.  A launch that starts inside a chunk (streaming) rebuilds org from the HBM pointers.
-    uint16_t *org = ring;      // [2][S]
-    int oc = 0;
-    if (act) {
-        const int tp = t_lo - 1, c0 = (tp / C) * C;
-        int s0 = j;
-        for (int tt = tp; tt > c0; --tt) s0 = ptr[(int64_t)tt * S + s0];
-        org[j] = (uint16_t)s0;
-    }
-    int par = 0;
-    double G;                 // column max (all states)
-    double Gp = INFINITY;     // the column max one step earlier (unknown at the first step of a launch)
-    int kg;
-    // End-of-step bookkeeping, one barrier: block arg-max (lowest index on ties; DPP wave max -> first
-    // lane holding it -> one LDS slot per wave -> every wave reduces the <= 16 slots) and one ballot mask
-    // per voiced wave marking the observed voiced states.
-    auto end_of_step = [&](double v, bool obs) {
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 2)
-        __syncthreads(); G = v; kg = 0; return;
-#endif
-        double m = row16_prefix_max(v);
-        m = dpp_fmax<0x142, 0xa>(m);   // row_bcast:15
-        m = dpp_fmax<0x143, 0xc>(m);   // row_bcast:31
-        const double wm = read_lane_f64(m, 63);
-        const unsigned long long eq = __ballot(v == wm);
-        if (!vp) {                     // wave-uniform
-            const unsigned long long om = __ballot(obs);
-            double ov = row16_prefix_max(obs ? v : -INFINITY);
-            ov = dpp_fmax<0x142, 0xa>(ov);
-            ov = dpp_fmax<0x143, 0xc>(ov);
-            if (lane == 0) omask[par * 16 + wid] = om;
-            if (lane == 63) vobs[par * 16 + wid] = ov;
-        }
-        if (lane == 0) {
-            rv[par * 16 + wid] = wm;
-            ri[par * 16 + wid] = eq ? vp * B + wlo + (int)__ffsll((long long)eq) - 1 : 0x7fffffff;
-        }
-        __syncthreads();
-        double a = -INFINITY;
-        int ai = 0x7fffffff;
-        if (lane < nw) { a = rv[par * 16 + lane]; ai = ri[par * 16 + lane]; }
-        const double pm = row16_prefix_max(a);
-        Gp = G;
-        G = read_lane_f64(pm, 15);
-        const unsigned long long eq2 = __ballot(a == G) & 0xffffull;
-        kg = __builtin_amdgcn_readlane(ai, eq2 ? (int)__ffsll((long long)eq2) - 1 : 0);
-        par ^= 1;
-    };
-    end_of_step(myv, observed);
-    if (p.live_states != nullptr && tid == 0 && vt_begin == 0) p.live_states[f0] = kg;
-
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
-    long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-#endif
-    const int lrlo = max(wlo - H, 0), lrhi = min(whi + H, B - 1);
-    const int lw0 = lrlo >> 6, lw1 = lrhi >> 6;
-    int cur = 0;
-    int n_list = 0;           // wave-steps that took the observed-sources-only path (wave-uniform)
-#ifdef AEGIS_LP_AHEAD
-    double lpa = 0.0, lpb = 0.0;
-    if (act) {
-        const int ta = min(t_lo, T - 1), tb2 = min(t_lo + 1, T - 1);
-        lpa = vp ? lunv[ta] : lobs[(int64_t)ta * os + b2c];
-        lpb = vp ? lunv[tb2] : lobs[(int64_t)tb2 * os + b2c];
-    }
-#endif
-    for (int t = t_lo; t < t_hi; ++t) {
-        VIT_TICK(5)
-#ifdef AEGIS_LP_AHEAD
-        // the step's observation was requested two steps ago (a load issued under a busy memory system may take longer
-        // than one step); rows beyond this launch's range are fetched and never used
-        const double lp = lpa;
-        lpa = lpb;
-        { const int tn = min(t + 2, T - 1); if (act) lpb = vp ? lunv[tn] : lobs[(int64_t)tn * os + b2c]; }
-#else
-        double lp = 0.0;
-        if (act) lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
-#endif
-        const int lpar = par ^ 1;      // parity the previous end_of_step wrote its lists under
-        // observed bins within reach of this wave's targets, [wlo - H, whi + H], span <= 3 mask words: their masks and
-        // the voiced waves' largest observed values are fetched here, far ahead of the list section that tests them
-        double vb[3];
-        unsigned long long mk[3];
-#pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const int wv = lw0 + u;
-            const bool okw = LT_LDS && wv <= lw1;
-            vb[u] = okw ? vobs[lpar * 16 + wv] : -INFINITY;
-            mk[u] = okw ? omask[lpar * 16 + wv] : 0ull;
-        }
-
-        const double *vi0 = valI + (cur * 2 + 0) * PADB + b2c;
-        const double *vi1 = valI + (cur * 2 + 1) * PADB + b2c;
-        const double *ve0 = valE + (cur * 2 + 0) * 2 * H;
-        const double *ve1 = valE + (cur * 2 + 1) * 2 * H;
-        // edge sources: table offset of (source e, this lane) = lane base + e*(W-1); pairs out of
-        // reach are redirected to the -inf sentinel (LDS copy) or predicated (global table).
-        // The opaque copy of b' keeps these cheap per-step integer ops from being hoisted out of
-        // the time loop into ~50 live registers.
-        int bl = b2c;
-        asm volatile("" : "+v"(bl));
-        // full table: [class][dd], class e resp. H+1+e, dd = b' - b + H; packed: row start + (dd - first dd of the row)
-        auto eoff_lo = [&](int e) { return PK ? pk_lo_start<H>(e) + bl : (bl + H) + e * (W - 1); };
-        auto eoff_hi = [&](int e) { return PK ? pk_hi_start<H>(e) + (bl - B + 2 * H - e) : (bl - B + 2 * H) + (H + 1) * W + e * (W - 1); };
-        const int reach_lo = act ? bl - H : 0x7fffffff;           // low source e in reach  <=> e >= reach_lo
-        const int reach_hi = act ? bl - (B - 2 * H) : -1;         // high source e in reach <=> e <= reach_hi
-
-        double best = -INFINITY;
-        int bi = 0;
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 32)
-        if (vp) {   // timing experiment: voiced waves skip all candidate work (values are wrong)
-#else
-        {
-#endif
-        // ---- unvoiced sources (v = 1): always the full band, two interleaved half chains ----------
-        double best1 = -INFINITY, best1b = -INFINITY;
-        int code1 = 0, code1b = 0;
-        constexpr int HALF = (W + 1) / 2;
-#pragma unroll
-        for (int d = 0; d < HALF; ++d) {
-            const double cand = vi1[d] + lti1[W - 1 - d];
-            if (cand > best1) code1 = d;
-            best1 = fmax(best1, cand);
-            if (HALF + d < W) {
-                const double candb = vi1[HALF + d] + lti1[W - 1 - HALF - d];
-                if (candb > best1b) code1b = HALF + d;
-                best1b = fmax(best1b, candb);
-            }
-        }
-        if (best1b > best1) { best1 = best1b; code1 = code1b; }
-        int src1 = b2c + code1 - H;
-#if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
-        if (wave_low) {     // low-edge sources precede the interior ones in state order: they win ties
-            double eb1 = -INFINITY;
-            int ec1 = 0;
-#pragma unroll
-            for (int e = 0; e < H; ++e) {
-                const bool ok = e >= reach_lo;
-                const int off = (LT_LDS && !ok) ? kSentinel : eoff_lo(e);
-                const double cand1 = (LT_LDS || ok) ? ve1[e] + lt_e1[off] : -INFINITY;
-                if (cand1 > eb1) ec1 = e;
-                eb1 = fmax(eb1, cand1);
-            }
-            if (eb1 >= best1) { best1 = eb1; src1 = ec1; }
-        }
-        if (wave_high) {    // high-edge sources follow the interior ones: they lose ties
-            double eb1 = -INFINITY;
-            int ec1 = 0;
-#pragma unroll
-            for (int e = 0; e < H; ++e) {
-                const bool ok = e <= reach_hi;
-                const int off = (LT_LDS && !ok) ? kSentinel : eoff_hi(e);
-                const double cand1 = (LT_LDS || ok) ? ve1[H + e] + lt_e1[off] : -INFINITY;
-                if (cand1 > eb1) ec1 = e;
-                eb1 = fmax(eb1, cand1);
-            }
-            if (eb1 > best1) { best1 = eb1; src1 = B - H + ec1; }
-        }
-#endif
-
-        VIT_TICK(0)
-        // ---- voiced sources (v = 0) ------------------------------------------------------------------
-        // Exact pruning.  Voiced states whose previous-frame observation was log(tiny) carry that -708
-        // in their value: value = log(tiny) + (best candidate out of the column before), and no candidate out of
-        // that column exceeds Gp + lmax_all (Gp = its maximum; rounding is monotone), so MUb = log(tiny) +
-        // (Gp + lmax_all) bounds every such state without a reduction over them.  No candidate built on one of
-        // them can then exceed MUb + lmax (lmax = largest log-transition of the block).  If that bound is
-        // strictly below the unvoiced chain's result in every lane of the wave, such sources can neither
-        // win nor tie anywhere in the wave, and only the observed voiced states -- a handful per frame,
-        // listed in ascending bin order by the previous step -- remain to be examined.
-        int src = 0;
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 8)
-        const bool list_only = true;
-#elif defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 16)
-        const bool list_only = false;
-#else
-        const double MUb = p.log_tiny + (Gp + blt.lmax_all);
-        const bool list_only = LT_LDS && __all(!act || (MUb + blt.lmax[0 * 2 + vp] < best1));
-#endif
-        n_list += list_only ? 1 : 0;
-        if (list_only) {
-            // Second exact prune, per source: an observed voiced source of value vo offers no lane more than
-            // vo + lmax; when that is strictly below the smallest unvoiced-chain result of the wave it can neither win
-            // nor tie (a voiced candidate only beats best1 by being >= it), so the per-lane work of the entry -- table
-            // lookup, add, compare, select -- is skipped on a scalar test.  94 % of the entries on the bench clips: most
-            // observed bins are sub-harmonic troughs with tiny probabilities.  The same test on the largest observed value
-            // of a voiced wave (one DPP max per voiced wave and step) skips a whole mask word without walking its bits.
-            double wmin1;
-            {
-                double mn = act ? -best1 : -INFINITY;      // min(best1) = -max(-best1)
-                mn = row16_prefix_max(mn);
-                mn = dpp_fmax<0x142, 0xa>(mn);
-                mn = dpp_fmax<0x143, 0xc>(mn);
-                wmin1 = -read_lane_f64(mn, 63);
-            }
-            const double lmax0 = blt.lmax[0 * 2 + vp];
-#pragma unroll
-            for (int u = 0; u < 3; ++u) {
-                const int w = lw0 + u;
-                // the same bound for a whole mask word: no observed state of voiced wave w is worth more than vobs[w]
-                if (vb[u] + lmax0 < wmin1) continue;
-                unsigned long long m = mk[u];
-                if (w == lw0) m &= ~0ull << (lrlo & 63);
-                if (w == lw1) m &= ~0ull >> (63 - (lrhi & 63));
-                m = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
-                    (unsigned)__builtin_amdgcn_readfirstlane((int)m);
-                while (m) {                                  // ascending bins: strict '>' keeps the lowest index
-                    const int bo = (w << 6) + (int)__ffsll((long long)m) - 1;
-                    m &= m - 1;
-                    const bool lo_e = bo < H, hi_e = bo > B - 1 - H;
-                    const double vo = (lo_e || hi_e) ? ve0[lo_e ? bo : bo - B + 2 * H] : valI[(cur * 2 + 0) * PADB + bo + H];
-                    if (vo + lmax0 < wmin1) continue;
-                    const int rowbase = !PK ? (lo_e ? bo : (hi_e ? bo - (B - 1 - 2 * H) : H)) * W
-                                            : lo_e ? pk_lo_start<H>(bo) - (H - bo)
-                                                   : (hi_e ? pk_hi_start<H>(bo - (B - H)) : pk_int_start<H>());   // scalar
-                    const int dd = b2c - bo + H;
-                    const int off = (act && (unsigned)dd < (unsigned)W) ? rowbase + dd : kSentinel;
-                    const double cand = vo + lt_e0[off];
-                    if (cand > best) src = bo;
-                    best = fmax(best, cand);
-                }
-            }
-        } else {
-            double besta = -INFINITY, bestb = -INFINITY;
-            int codea = 0, codeb = 0;
-#pragma unroll
-            for (int d = 0; d < HALF; ++d) {
-                const double cand = vi0[d] + lti0[W - 1 - d];
-                if (cand > besta) codea = d;
-                besta = fmax(besta, cand);
-                if (HALF + d < W) {
-                    const double candb = vi0[HALF + d] + lti0[W - 1 - HALF - d];
-                    if (candb > bestb) codeb = HALF + d;
-                    bestb = fmax(bestb, candb);
-                }
-            }
-            if (bestb > besta) { besta = bestb; codea = codeb; }
-            best = besta;
-            src = b2c + codea - H;
-#if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
-            if (wave_low) {
-                double eb = -INFINITY;
-                int ec = 0;
-#pragma unroll
-                for (int e = 0; e < H; ++e) {
-                    const bool ok = e >= reach_lo;
-                    const int off = (LT_LDS && !ok) ? kSentinel : eoff_lo(e);
-                    const double cand = (LT_LDS || ok) ? ve0[e] + lt_e0[off] : -INFINITY;
-                    if (cand > eb) ec = e;
-                    eb = fmax(eb, cand);
-                }
-                if (eb >= best) { best = eb; src = ec; }
-            }
-            if (wave_high) {
-                double eb = -INFINITY;
-                int ec = 0;
-#pragma unroll
-                for (int e = 0; e < H; ++e) {
-                    const bool ok = e <= reach_hi;
-                    const int off = (LT_LDS && !ok) ? kSentinel : eoff_hi(e);
-                    const double cand = (LT_LDS || ok) ? ve0[H + e] + lt_e0[off] : -INFINITY;
-                    if (cand > eb) ec = e;
-                    eb = fmax(eb, cand);
-                }
-                if (eb > best) { best = eb; src = B - H + ec; }
-            }
-#endif
-        }
-        VIT_TICK(1)
-        bi = src;
-        if (best1 > best) { best = best1; bi = B + src1; }
-        // the one out-of-band candidate that can win: the previous column's arg-max
-        {
-            const int bg = kg >= B ? kg - B : kg;
-            const int dist = bg > b2c ? bg - b2c : b2c - bg;
-            if (dist > H) {
-                const double cand = G + p.log_tiny;
-                if (cand > best || (cand == best && kg < bi)) { best = cand; bi = kg; }
-            }
-        }
-        }
-        myv = -INFINITY;
-        observed = false;
-        if (act) {
-            myv = lp + best;
-            observed = !vp && lp != p.log_tiny;
-            store_value(cur ^ 1, myv);
-            ptr[(int64_t)t * S + j] = (uint16_t)bi;
-            const uint16_t o = ((t - 1) % C == 0) ? (uint16_t)bi : org[oc * S + bi];
-            org[(oc ^ 1) * S + j] = o;
-            if (t % C == 0 || t == T - 1) cmap[(int64_t)((t - 1) / C) * S + j] = o;
-        }
-        oc ^= 1;
-        VIT_TICK(2)
-        end_of_step(myv, observed);
-        VIT_TICK(3)
-        if (p.live_states != nullptr && tid == 0) p.live_states[f0 + t] = kg;
-        cur ^= 1;
-        VIT_TICK(4)
-    }
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
-    if (blockIdx.x == 0 && lane == 0) {
-        for (int k = 0; k < 6; ++k) atomicAdd((unsigned long long *)&g_vit_dbg[wid * 8 + k], (unsigned long long)tacc[k]);
-        atomicAdd((unsigned long long *)&g_vit_dbg[wid * 8 + 7], (unsigned long long)(t_hi - t_lo));
-    }
-#endif
-
-    if (p.vstats != nullptr && lane == 0 && t_hi > t_lo) {
-        atomicAdd(&p.vstats[0], (unsigned long long)(t_hi - t_lo));
-        atomicAdd(&p.vstats[1], (unsigned long long)n_list);
-    }
-    if (t_hi < T) {                       // more launches follow: hand the column over
-        if (act) vst[j] = myv;
-        return;
-    }
-    if (tid == 0) {
-        int s = kg;
-        for (int cc = nch - 1; cc >= 0; --cc) { bnd[cc] = s; s = cmap[(int64_t)cc * S + s]; }
-        states[0] = s;
-    }
-    __threadfence();
-    __syncthreads();
-    for (int cc = tid; cc < nch; cc += nthr) {
-        const int te = min((cc + 1) * C, T - 1);
-        int s = bnd[cc];
-        states[te] = s;
-        for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
-    }
-}
-
-#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
-hipError_t viterbi_debug_fetch(long long *dst, bool reset) {
-    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vit_dbg), sizeof(long long) * 128);
-    if (e == hipSuccess && reset) { static long long z[128]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_vit_dbg), z, sizeof(z)); }
-    return e;
-}
-#else
-hipError_t viterbi_debug_fetch(long long *dst, bool) { for (int i = 0; i < 128; ++i) dst[i] = 0; return hipSuccess; }
-#endif
-
-template <int H>
-static size_t viterbi_band_lds(const PassParams &p, bool lt_lds) {
-    const int B = p.n_bins, S = 2 * B;
-    const int PADB = (B + 2 * H + 64 + 7) & ~7;
-    size_t b = (((size_t)(4 * PADB + 8 * H + 96) * 8 + 32 * 4 + (size_t)2 * S * 2 + 15) / 16) * 16;
-    if (lt_lds) b += band_table_packed(H) ? (size_t)2 * pk_size<H>() * 8 : (size_t)4 * p.n_cls * (2 * H + 1) * 8;
-    return b;
-}
-
-// ------------------------------------------------------------------------------------------
 // Kernel 5a: f0 / voiced decode (pitch.py: f0 = freqs[state % B], voiced = state < B).
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void decode_kernel(PassParams p, DevTables tb) {
@@ -1625,13 +959,6 @@ void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *
 // ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
-static size_t viterbi_lds_bytes(const PassParams &p, bool with_lt) {
-    const int S = 2 * p.n_bins, SP = (S + 63) & ~63;
-    size_t b = ((size_t)(2 * SP + 32) * 8 + 32 * 4 + (size_t)kViterbiChunk * S * 2 + 15) / 16 * 16;
-    if (with_lt) b += (size_t)4 * p.n_cls * p.width * 8;
-    return b;
-}
-
 hipError_t viterbi_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(frame_yin_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1639,14 +966,7 @@ hipError_t viterbi_configure() {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(pyin_obs_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);       // + 832 B static
     if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<25, true>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<50, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    return viterbi_set_lds_limits();
 }
 
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
@@ -1674,53 +994,6 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     const size_t lds = (size_t)(TN + waves * (YN + UN)) * 8;
     const int64_t per_wg = (int64_t)waves * fpw;
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)((p.n_sel + per_wg - 1) / per_wg)), dim3(64 * waves), lds, s, p, t, fpw);
-}
-// AEGIS_VITERBI_EXCLUSIVE=<clips> (experiment knob, default off): launches of up to that many clips ask for the whole 160 KB
-// of LDS, so that no frame-stage workgroup can be placed on the same CU.  Measured: no gain (64 clips: 83.6 vs 78.9 ms) --
-// what slows the Viterbi is frame-stage code on the NEIGHBOURING CU (shared instruction cache), which the CU-partitioned
-// streams of aegis_api.hip::split_streams avoid.
-static size_t viterbi_launch_lds(size_t need, int n_clips) {
-    static const int limit = [] { const char *e = std::getenv("AEGIS_VITERBI_EXCLUSIVE"); return e ? std::atoi(e) : 0; }();
-    return n_clips <= limit ? std::max<size_t>(need, 160 * 1024) : need;
-}
-
-hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {
-    if (p.n_clips == 0) return hipSuccess;
-    const int S = 2 * p.n_bins;
-    const int BP = (p.n_bins + 63) & ~63;
-    if (p.n_cls == p.width && 2 * BP <= 1024 && p.n_bins >= 4 * p.half_width + 128) {
-        // band-specialised kernels for the two hop/sr ratios the reference uses (44.1k and 22.05k at hop 512)
-        if (p.half_width == 25 && viterbi_band_lds<25>(p, true) <= 160 * 1024) {
-            BandLT<25> blt;
-            for (int q = 0; q < 4; ++q) {
-                std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 25) * p.width, sizeof(blt.v[q]));
-                blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width,
-                                                host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
-            }
-            blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
-            hipLaunchKernelGGL((viterbi_band_kernel<25, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
-                               viterbi_launch_lds(viterbi_band_lds<25>(p, true), p.n_clips), s, p, t, blt);
-            return hipGetLastError();
-        }
-        if (p.half_width == 50 && t.lt_pack != nullptr && viterbi_band_lds<50>(p, true) <= 160 * 1024) {
-            BandLT<50> blt;
-            for (int q = 0; q < 4; ++q) {
-                std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + 50) * p.width, sizeof(blt.v[q]));
-                blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width,
-                                                host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
-            }
-            blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
-            hipLaunchKernelGGL((viterbi_band_kernel<50, true>), dim3((unsigned)p.n_clips), dim3(2 * BP),
-                               viterbi_launch_lds(viterbi_band_lds<50>(p, true), p.n_clips), s, p, t, blt);
-            return hipGetLastError();
-        }
-    }
-    const int nthr = (S + 63) & ~63;
-    const bool with_lt = viterbi_lds_bytes(p, true) <= 160 * 1024;
-    const size_t lds = viterbi_lds_bytes(p, with_lt);
-    if (nthr > 1024 || lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(viterbi_kernel, dim3((unsigned)p.n_clips), dim3(nthr), lds, s, p, t, with_lt ? 1 : 0);
-    return hipGetLastError();
 }
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_frames == 0 || !(p.stages & 0x4u)) return;

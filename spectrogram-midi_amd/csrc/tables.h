@@ -45,7 +45,7 @@ struct Tables {
     std::vector<double> boltz_exp;     // [n]    e^-2k
     std::vector<double> log_trans_band; // [4][n_cls][width]  (v*2+v') major
     std::vector<double> log_trans_pack; // [2 (stay, switch)][3H^2+3H+2]: the band table without duplicate blocks and
-                                        // without the unreachable parts of the edge rows (kernels.hip pk_*); empty if
+                                        // without the unreachable parts of the edge rows (viterbi.hip pk_*); empty if
                                         // the (v,v') blocks are not pairwise identical
     std::vector<double> freqs;         // [n_bins]
     std::vector<double> twiddle;       // [n_fft][2]  cos, sin of -2*pi*m/n_fft

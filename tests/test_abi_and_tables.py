@@ -97,7 +97,7 @@ def test_banded_transition_table(host_handle):
 
 @pytest.mark.parametrize("sr,H", [(44100, 25), (22050, 50)])
 def test_packed_transition_table(sr, H):
-    """The LDS copy of the band table (csrc/kernels.hip pk_*): blocks (0,0) == (1,1) and (0,1) == (1,0) are stored once,
+    """The LDS copy of the band table (csrc/viterbi.hip pk_*): blocks (0,0) == (1,1) and (0,1) == (1,0) are stored once,
     edge rows only over the targets that exist.  Every entry of the full table must be found at its packed index."""
     h = _lib.Handle(sample_rate=sr, device=-1)
     W, B = 2 * H + 1, 441
