@@ -50,6 +50,9 @@ struct aegis_handle {
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
+    int64_t chunk_tail = 256;                 // smallest of the shrinking last chunks (AEGIS_CHUNK_TAIL, 0 = none)
+    int64_t balanced_chunk = 256;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
+    int balanced_min = 56;                    // fewest clips of a balanced pass (AEGIS_BALANCED_MIN)
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
@@ -268,6 +271,9 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
+    if (const char *e = std::getenv("AEGIS_CHUNK_TAIL")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->chunk_tail = v; }
+    if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
+    if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
     if (const char *e = std::getenv("AEGIS_RAMP_K")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 64) h->ramp_k = (int)v; }
     if (const char *e = std::getenv("AEGIS_CU_SPLIT")) h->split_limit = std::atoi(e);
     CRTHIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, c.device));
@@ -420,7 +426,14 @@ static aegis_handle::SplitSet *split_streams(aegis_handle *h, int n_clips) {
         const int v = idx == 0 ? 64 : 128;
         uint32_t fm[8], vm[8];
         for (int w = 0; w < 8; ++w) { fm[w] = 0; vm[w] = 0; }
-        for (int i = 0; i < 256; ++i) (i < 256 - v ? fm : vm)[i >> 5] |= 1u << (i & 31);
+        // AEGIS_CU_FRAME=<n> (experiment knob): the frame stage's mask covers CUs 0..n-1 instead of the complement of the
+        // Viterbi's (256: the whole device, sharing the Viterbi's CUs)
+        int nf = 256 - v;
+        if (const char *e = std::getenv("AEGIS_CU_FRAME")) nf = std::min(256, std::max(32, std::atoi(e)));
+        for (int i = 0; i < 256; ++i) {
+            if (i < nf) fm[i >> 5] |= 1u << (i & 31);
+            if (i >= 256 - v) vm[i >> 5] |= 1u << (i & 31);
+        }
         if (hipExtStreamCreateWithCUMask(&ss.frame_a, 8, fm) != hipSuccess || hipExtStreamCreateWithCUMask(&ss.frame_b, 8, fm) != hipSuccess ||
             hipExtStreamCreateWithCUMask(&ss.viterbi, 8, vm) != hipSuccess) {
             (void)hipGetLastError();
@@ -521,14 +534,36 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // launches.  Boundaries: frame 0, then 1 + (multiple of kViterbiChunk) so that every launch starts on a
         // back-pointer-map boundary.  Chunks start at a quarter of time_chunk and grow by 1.25x (the frame stage is
         // faster than the Viterbi per column, so the Viterbi stream never waits after the first chunk).
-        const int64_t kTimeChunk = h->time_chunk;      // multiple of kViterbiChunk
+        //
+        // Balanced passes: on the CU-partitioned streams (split_streams) a pass of 56..64 clips keeps the frame stage's 192
+        // CUs as long per column as the Viterbi keeps its 64 (3.3 vs 3.2 us), so neither may wait for the other: chunks
+        // of one small size (growing chunks make the Viterbi wait a quarter of each), alternating over the two frame
+        // streams so that one chunk's FFT kernel overlaps the previous chunk's latency-bound observation kernel
+        // (64 clips x 180 s: 59.5 -> 55.8 ms; measured worse below 56 clips and on unpartitioned passes).
+        const bool balanced = py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
+                              h->split_limit > 0 && nc <= h->split_limit && nc <= 128;
+        const int64_t kTimeChunk = balanced ? h->balanced_chunk : h->time_chunk;      // multiple of kViterbiChunk
         std::vector<int64_t> cb{0};
-        if (py && maxF > kTimeChunk + kTimeChunk / 2) {
+        if (balanced && maxF > 2 * kTimeChunk) {
+            for (int64_t b = 1 + kTimeChunk; b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
+        } else if (py && maxF > kTimeChunk + kTimeChunk / 2) {
             int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
-            while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
+            // The pass ends with the Viterbi of its last chunk running alone, so the last chunks shrink again: halves of
+            // time_chunk down to chunk_tail steps (AEGIS_CHUNK_TAIL, 0 = one long last chunk).
+            std::vector<int64_t> tail;
+            if (h->chunk_tail > 0)
+                for (int64_t sz = kTimeChunk / 2; sz >= h->chunk_tail && sz >= kViterbiChunk; sz /= 2) tail.push_back(sz / kViterbiChunk * kViterbiChunk);
+            int64_t tail_sum = 0;
+            for (int64_t v : tail) tail_sum += v;
+            while (cb.back() + kTimeChunk + kTimeChunk / 2 + tail_sum < maxF) {
                 step = std::min<int64_t>(kTimeChunk, (step * h->chunk_growth_pct / 100 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
                 cb.push_back(cb.back() + step);
+            }
+            const int64_t big = (maxF - cb.back() - tail_sum) / kViterbiChunk * kViterbiChunk;
+            if (!tail.empty() && big >= kTimeChunk / 2) {
+                cb.push_back(cb.back() + big);
+                for (size_t i = 0; i + 1 < tail.size(); ++i) cb.push_back(cb.back() + tail[i]);      // the last one runs to maxF
             }
         }
         cb.push_back(maxF);
@@ -554,7 +589,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
         // first four (short) chunks, whose kernels are too small to fill the chip on their own.
         const bool two_fs = py && nk > 2 && nc >= 128;
-        const int ramp_k = (py && nk > 2 && !two_fs) ? h->ramp_k : 0;
+        const int ramp_k = (py && nk > 2 && !two_fs) ? (balanced ? nk : h->ramp_k) : 0;
         const bool use_fb = two_fs || ramp_k > 0;
         while ((int)h->sync_events.size() < EV_CHUNK0 + nk) {
             hipEvent_t e;

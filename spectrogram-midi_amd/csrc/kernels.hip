@@ -96,45 +96,54 @@ __host__ __device__ inline int frame_en_stride(int max_period) {
 //   A  j <  8 nA          e[j] stored                      (nA blocks cover lags 0..max_period)
 //   B  8 nA <= j < 1024   chain only
 //   C  j = 1024 + tau     row[tau] = e[1024 + tau] - e[tau]
-// `fetch(j0, a, b)` returns samples j0..j0+7 of the lane's frame; the next block is requested before the current
-// block's eight dependent adds.  The row is over-written in whole blocks (entries past max_period are never read).
+// `fetch(j0, a, b)` returns samples j0..j0+7 of the lane's frame; a block is requested four blocks ahead of the
+// chain of the blocks before it.  The row is over-written in whole blocks (entries past max_period are never read).
 template <bool SQUARED, typename Fetch>
 __device__ __forceinline__ void energy_walk(Fetch fetch, float *__restrict__ row, int mp) {
-    const int nA = (mp + 8) >> 3;
-    float4 a, b, na, nb;
-    fetch(0, a, b);
+    const int nA = (mp + 8) >> 3, nblk = 128 + nA;
+    // four blocks (32 samples) are requested while the previous four are chained: eight dependent adds take less time
+    // than an LDS read returns in beside another workgroup's FFT passes, thirty-two do not
+    float4 cur[4][2], nxt[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch(8 * u, cur[u][0], cur[u][1]);
     float e = 0.0f;                 // 0 + x*x == x*x exactly: the first add reproduces np.cumsum's first element
-    int j0 = 0;
 #define AEGIS_SQ(x) (SQUARED ? (x) : (x) * (x))
-#define AEGIS_CHAIN8(ea, eb)                                                                     \
+#define AEGIS_CHAIN8(a, b, ea, eb)                                                               \
     { float sq;                                                                                  \
       sq = AEGIS_SQ(a.x); e = e + sq; ea.x = e;  sq = AEGIS_SQ(a.y); e = e + sq; ea.y = e;       \
       sq = AEGIS_SQ(a.z); e = e + sq; ea.z = e;  sq = AEGIS_SQ(a.w); e = e + sq; ea.w = e;       \
       sq = AEGIS_SQ(b.x); e = e + sq; eb.x = e;  sq = AEGIS_SQ(b.y); e = e + sq; eb.y = e;       \
       sq = AEGIS_SQ(b.z); e = e + sq; eb.z = e;  sq = AEGIS_SQ(b.w); e = e + sq; eb.w = e; }
-    for (int k = 0; k < nA; ++k, j0 += 8) {
-        fetch(j0 + 8, na, nb);
-        float4 ea, eb;
-        AEGIS_CHAIN8(ea, eb)
-        *reinterpret_cast<float4 *>(row + j0) = ea;
-        *reinterpret_cast<float4 *>(row + j0 + 4) = eb;
-        a = na; b = nb;
-    }
-    for (; j0 < 1024; j0 += 8) {
-        fetch(j0 + 8, na, nb);
-        float4 ea, eb;
-        AEGIS_CHAIN8(ea, eb)
-        a = na; b = nb;
-    }
-    for (int k = 0; k < nA; ++k, j0 += 8) {
-        fetch(j0 + 8, na, nb);
-        float4 ea, eb;
-        AEGIS_CHAIN8(ea, eb)
-        float *r = row + 8 * k;
-        const float4 lo0 = *reinterpret_cast<const float4 *>(r), lo1 = *reinterpret_cast<const float4 *>(r + 4);
-        *reinterpret_cast<float4 *>(r) = make_float4(ea.x - lo0.x, ea.y - lo0.y, ea.z - lo0.z, ea.w - lo0.w);
-        *reinterpret_cast<float4 *>(r + 4) = make_float4(eb.x - lo1.x, eb.y - lo1.y, eb.z - lo1.z, eb.w - lo1.w);
-        a = na; b = nb;
+    for (int b0 = 0; b0 < nblk; b0 += 4) {
+        // blocks past the walk's end are fetched (inside the staging area, or bounds-checked) and never used
+#pragma unroll
+        for (int u = 0; u < 4; ++u) fetch(8 * (b0 + 4 + u), nxt[u][0], nxt[u][1]);
+        float4 lo[4][2];
+        if (b0 + 3 >= 128) {        // phase C rows of this group, requested before the chain that needs them
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = min(max(b0 + u - 128, 0), nA - 1);
+                lo[u][0] = *reinterpret_cast<const float4 *>(row + 8 * k);
+                lo[u][1] = *reinterpret_cast<const float4 *>(row + 8 * k + 4);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int blk = b0 + u;
+            if (blk >= nblk) break;
+            float4 ea, eb;
+            AEGIS_CHAIN8(cur[u][0], cur[u][1], ea, eb)
+            if (blk < nA) {
+                *reinterpret_cast<float4 *>(row + 8 * blk) = ea;
+                *reinterpret_cast<float4 *>(row + 8 * blk + 4) = eb;
+            } else if (blk >= 128) {
+                float *r = row + 8 * (blk - 128);
+                *reinterpret_cast<float4 *>(r) = make_float4(ea.x - lo[u][0].x, ea.y - lo[u][0].y, ea.z - lo[u][0].z, ea.w - lo[u][0].w);
+                *reinterpret_cast<float4 *>(r + 4) = make_float4(eb.x - lo[u][1].x, eb.y - lo[u][1].y, eb.z - lo[u][1].z, eb.w - lo[u][1].w);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
     }
 #undef AEGIS_CHAIN8
 #undef AEGIS_SQ
@@ -191,7 +200,18 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             v[r] = (g.live && idx >= 0 && idx < g.n) ? p.pcm[g.base + idx] : 0.0f;
         }
     };
+    // Frame i + 1 of the workgroup is normally the next frame of frame i's clip: one comparison against the end of the
+    // clip's selection then replaces locate()'s binary search, a chain of dependent loads each frame had to wait for.
+    auto locate_next = [&](const Geo &g, int i, int64_t sel_end) {
+        if (i < nfr && g.live && fs0 + i < sel_end) {
+            Geo n = g;
+            n.start += p.hop; n.f += 1; n.o += 1;
+            return n;
+        }
+        return locate(i);
+    };
     Geo geo = locate(0);
+    int64_t geo_sel_end = geo.live ? p.sel_off[geo.c + 1] : 0;
     float nx[8];
     fetch(geo, nx);
     Fft8Tw twr;
@@ -209,7 +229,9 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         // The workgroup's frames are normally consecutive frames of one clip: their samples (one contiguous stretch,
         // <= 15 hops + 2048 samples) are staged with coalesced loads in the FFT buffer + frame area, which nothing
         // uses yet, so the serial walk reads LDS instead of waiting for a global load per eight samples.
-        const Geo g0 = locate(0), gl = locate(nfr - 1);
+        const Geo g0 = geo;
+        Geo gl = g0;
+        if (fs0 + nfr - 1 < geo_sel_end) { gl.start += (int64_t)(nfr - 1) * p.hop; } else gl = locate(nfr - 1);
         const int64_t span = (int64_t)(nfr - 1) * p.hop + 2048;
         const bool staged = g0.c == gl.c && p.hop == 512 && span + 4 * (span >> 9) <= 10240;
         float *stage = reinterpret_cast<float *>(z);
@@ -221,6 +243,9 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             }
             __syncthreads();
         }
+        // The walk is one dependent add after another: beside another workgroup's FFT waves on the same SIMD it would
+        // get an issue slot only when they stall, while this workgroup's other three waves wait for it -- raise it.
+        if (wid == 0) __builtin_amdgcn_s_setprio(3);
         if (wid == 0 && lane < nfr) {
             float *row = en + lane * en_stride;
             if (staged) {
@@ -241,6 +266,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 }, row, mp);
             }
         }
+        if (wid == 0) __builtin_amdgcn_s_setprio(0);
         if (staged) __syncthreads();                     // the staging area becomes the FFT buffer and the frame again
     }
     // (the first barrier of the frame loop publishes the rows)
@@ -261,7 +287,11 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             fidx[h] = f; flive[h] = live;
 #pragma unroll
             for (int r = 0; r < 8; ++r) xs[tid + r * 256] = nx[r];
-            geo = locate(pr + h + 1);
+            {
+                const int cprev = geo.c;
+                geo = locate_next(geo, pr + h + 1, geo_sel_end);
+                if (geo.live && geo.c != cprev) geo_sel_end = p.sel_off[geo.c + 1];
+            }
             fetch(geo, nx);                                   // in flight under everything below
             __syncthreads();
             FRM_TICK(1)

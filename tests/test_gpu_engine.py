@@ -278,3 +278,25 @@ def test_two_frame_streams_large_batch(monkeypatch):
         for k in ref[i]:
             np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"clip {i} {k}")
     h.close(); ref_h.close()
+
+
+def test_balanced_schedule_small_chunks(monkeypatch):
+    """Passes of 56..64 clips on the CU-partitioned streams run on equal chunks alternating over two frame streams
+    (aegis_api.hip, "balanced passes").  With AEGIS_BALANCED_CHUNK=32 a batch of 60 short ragged clips (one empty)
+    takes that schedule through dozens of chunk hand-overs; a handle with the schedule switched off analyses the same
+    clips.  Bit-identical."""
+    rng = np.random.default_rng(5)
+    base = signals.guitar_clip(8.0, seed=23)
+    clips = [base[o:o + n].copy() for o, n in zip(rng.integers(0, 150000, 60), rng.integers(30000, 190000, 60))]
+    clips[11] = np.zeros(0, np.float32)
+    monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "0")
+    ref_h = _lib.Handle()
+    ref = ref_h.analyze_batch(clips)
+    monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "32")
+    h = _lib.Handle()
+    got = h.analyze_batch(clips)
+    monkeypatch.delenv("AEGIS_BALANCED_CHUNK")
+    for i in range(len(clips)):
+        for k in ref[i]:
+            np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"clip {i} {k}")
+    h.close(); ref_h.close()

@@ -6,13 +6,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from spectrogram_midi_amd import _lib, signals
 y = signals.guitar_clip(180.0, seed=1)
-clips = [np.roll(y, 1000 * i) for i in range(8)]
+clips = [np.roll(y, 1000 * i) for i in range(64)]
 h = _lib.Handle()
 h.analyze_batch(clips)
 v = h.debug_fetch("frame_cycles")
 names = ["energy prologue", "wait samples", "rms + fwd fft", "separate + power", "mel", "inverse fft", "difference store"]
 for base, who in ((0, "thread 0 (wave 0)"), (8, "thread 64 (wave 1)")):
     tot = int(v[base:base + 7].sum())
-    print(who, "total", tot, "cycles (100 MHz timer ticks x ~24 = shader cycles)" )
+    print(who, "total", tot, "clock64 ticks" )
     for n, c in zip(names, v[base:base + 7]):
         print(f"  {n:18s} {int(c):9d}  {100.0 * c / max(tot, 1):5.1f} %")
