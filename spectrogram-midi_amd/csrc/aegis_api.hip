@@ -50,8 +50,7 @@ struct aegis_handle {
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
-    int64_t chunk_tail = 256;                 // smallest of the shrinking last chunks (AEGIS_CHUNK_TAIL, 0 = none)
-    int64_t balanced_chunk = 256;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
+    int64_t balanced_chunk = 384;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
     int balanced_min = 56;                    // fewest clips of a balanced pass (AEGIS_BALANCED_MIN)
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
@@ -271,7 +270,6 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
-    if (const char *e = std::getenv("AEGIS_CHUNK_TAIL")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->chunk_tail = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
     if (const char *e = std::getenv("AEGIS_RAMP_K")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 64) h->ramp_k = (int)v; }
@@ -549,21 +547,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         } else if (py && maxF > kTimeChunk + kTimeChunk / 2) {
             int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
-            // The pass ends with the Viterbi of its last chunk running alone, so the last chunks shrink again: halves of
-            // time_chunk down to chunk_tail steps (AEGIS_CHUNK_TAIL, 0 = one long last chunk).
-            std::vector<int64_t> tail;
-            if (h->chunk_tail > 0)
-                for (int64_t sz = kTimeChunk / 2; sz >= h->chunk_tail && sz >= kViterbiChunk; sz /= 2) tail.push_back(sz / kViterbiChunk * kViterbiChunk);
-            int64_t tail_sum = 0;
-            for (int64_t v : tail) tail_sum += v;
-            while (cb.back() + kTimeChunk + kTimeChunk / 2 + tail_sum < maxF) {
+            while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
                 step = std::min<int64_t>(kTimeChunk, (step * h->chunk_growth_pct / 100 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
                 cb.push_back(cb.back() + step);
-            }
-            const int64_t big = (maxF - cb.back() - tail_sum) / kViterbiChunk * kViterbiChunk;
-            if (!tail.empty() && big >= kTimeChunk / 2) {
-                cb.push_back(cb.back() + big);
-                for (size_t i = 0; i + 1 < tail.size(); ++i) cb.push_back(cb.back() + tail[i]);      // the last one runs to maxF
             }
         }
         cb.push_back(maxF);

@@ -83,69 +83,91 @@ __device__ __forceinline__ void load8(const float *__restrict__ x, int64_t n, in
     }
 }
 
-// floats per running-energy row: lags 0..max_period rounded up to whole blocks of 8 (the walk stores whole blocks),
+// floats per running-energy row: lags 0..max_period rounded up to whole groups of 32 (the walk stores whole groups),
 // then to a multiple of 4 whose quarter is odd, so that the 16-byte accesses of 16 lanes (one row each) fall on 16
 // distinct bank groups
 __host__ __device__ inline int frame_en_stride(int max_period) {
-    int s = (max_period + 8) & ~7;
+    int s = ((max_period + 32) >> 5) << 5;          // whole groups of 32 lags (energy_walk)
     if (((s >> 2) & 1) == 0) s += 4;
     return s;
 }
 
-// One lane's walk of np.cumsum(frame**2) (float32, strictly sequential) in straight-line blocks of 8 samples:
-//   A  j <  8 nA          e[j] stored                      (nA blocks cover lags 0..max_period)
-//   B  8 nA <= j < 1024   chain only
+// One lane's walk of np.cumsum(frame**2) (float32, strictly sequential) in straight-line groups of 32 samples:
+//   A  j <  32 nG         e[j] stored                      (nG groups cover lags 0..max_period)
+//   B  32 nG <= j < 1024  chain only
 //   C  j = 1024 + tau     row[tau] = e[1024 + tau] - e[tau]
-// `fetch(j0, a, b)` returns samples j0..j0+7 of the lane's frame; a block is requested four blocks ahead of the
-// chain of the blocks before it.  The row is over-written in whole blocks (entries past max_period are never read).
+// `fetch(j0, a, b)` returns samples j0..j0+7 of the lane's frame.  A group's eight fetches are issued while the group
+// before it is chained, into the other of two register sets (no copies), and little but the 32 dependent adds and the
+// group's own row traffic sits between two groups (tools/ubench_walk.hip times the variants on an idle CU).  The row is over-written in whole groups (entries past
+// max_period are never read; frame_en_stride leaves room for them).
+__host__ __device__ inline int energy_groups(int max_period) { return (max_period + 32) >> 5; }
+// The same walk as one plain loop, one sample at a time (rare workgroups: frames of two clips, or a hop the staging
+// area cannot hold): small code, no concern for speed.  `sample(j)` returns sample j of the lane's frame.
+template <typename Sample>
+__device__ __forceinline__ void energy_walk_plain(Sample sample, float *__restrict__ row, int mp) {
+    const int n = 32 * energy_groups(mp);
+    float e = 0.0f;
+    for (int j = 0; j < 1024 + n; ++j) {
+        const float x = sample(j);
+        e = e + x * x;
+        if (j < n) row[j] = e;
+        else if (j >= 1024) row[j - 1024] = e - row[j - 1024];
+    }
+}
 template <bool SQUARED, typename Fetch>
 __device__ __forceinline__ void energy_walk(Fetch fetch, float *__restrict__ row, int mp) {
-    const int nA = (mp + 8) >> 3, nblk = 128 + nA;
-    // four blocks (32 samples) are requested while the previous four are chained: eight dependent adds take less time
-    // than an LDS read returns in beside another workgroup's FFT passes, thirty-two do not
-    float4 cur[4][2], nxt[4][2];
+    const int nG = energy_groups(mp);
+    float4 ra[8], rb[8];            // two register sets: one group is chained while the next one's samples arrive
 #pragma unroll
-    for (int u = 0; u < 4; ++u) fetch(8 * u, cur[u][0], cur[u][1]);
+    for (int u = 0; u < 4; ++u) fetch(8 * u, ra[2 * u], ra[2 * u + 1]);
     float e = 0.0f;                 // 0 + x*x == x*x exactly: the first add reproduces np.cumsum's first element
 #define AEGIS_SQ(x) (SQUARED ? (x) : (x) * (x))
-#define AEGIS_CHAIN8(a, b, ea, eb)                                                               \
+#define AEGIS_CHAIN4(q, o)                                                                       \
     { float sq;                                                                                  \
-      sq = AEGIS_SQ(a.x); e = e + sq; ea.x = e;  sq = AEGIS_SQ(a.y); e = e + sq; ea.y = e;       \
-      sq = AEGIS_SQ(a.z); e = e + sq; ea.z = e;  sq = AEGIS_SQ(a.w); e = e + sq; ea.w = e;       \
-      sq = AEGIS_SQ(b.x); e = e + sq; eb.x = e;  sq = AEGIS_SQ(b.y); e = e + sq; eb.y = e;       \
-      sq = AEGIS_SQ(b.z); e = e + sq; eb.z = e;  sq = AEGIS_SQ(b.w); e = e + sq; eb.w = e; }
-    for (int b0 = 0; b0 < nblk; b0 += 4) {
-        // blocks past the walk's end are fetched (inside the staging area, or bounds-checked) and never used
+      sq = AEGIS_SQ(q.x); e = e + sq; o.x = e;  sq = AEGIS_SQ(q.y); e = e + sq; o.y = e;         \
+      sq = AEGIS_SQ(q.z); e = e + sq; o.z = e;  sq = AEGIS_SQ(q.w); e = e + sq; o.w = e; }
+    // group g from `cur`, group g + 1 requested into `nxt` first (past the last group: inside the staging area or
+    // bounds-checked, never used).  Each phase is its own straight-line loop, so the wait before a chain counts exactly
+    // the eight requests behind the samples it needs.
+    auto group = [&](auto phase, float4 (&cur)[8], float4 (&nxt)[8], int g) {
+        constexpr int PH = decltype(phase)::value;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) fetch(8 * (b0 + 4 + u), nxt[u][0], nxt[u][1]);
-        float4 lo[4][2];
-        if (b0 + 3 >= 128) {        // phase C rows of this group, requested before the chain that needs them
+        for (int u = 0; u < 4; ++u) fetch(32 * (g + 1) + 8 * u, nxt[2 * u], nxt[2 * u + 1]);
+        float4 o[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int k = min(max(b0 + u - 128, 0), nA - 1);
-                lo[u][0] = *reinterpret_cast<const float4 *>(row + 8 * k);
-                lo[u][1] = *reinterpret_cast<const float4 *>(row + 8 * k + 4);
+        for (int u = 0; u < 8; ++u) AEGIS_CHAIN4(cur[u], o[u])
+        if (PH == 0) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) *reinterpret_cast<float4 *>(row + 32 * g + 4 * u) = o[u];
+        }
+        if (PH == 2) {              // the row reads wait here, 17 times per walk; ahead of the chain they would put
+            float *r = row + 32 * (g - 32);      // sixteen requests in flight, more than a wait can count
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const float4 lo = *reinterpret_cast<const float4 *>(r + 4 * u);
+                *reinterpret_cast<float4 *>(r + 4 * u) = make_float4(o[u].x - lo.x, o[u].y - lo.y, o[u].z - lo.z, o[u].w - lo.w);
             }
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int blk = b0 + u;
-            if (blk >= nblk) break;
-            float4 ea, eb;
-            AEGIS_CHAIN8(cur[u][0], cur[u][1], ea, eb)
-            if (blk < nA) {
-                *reinterpret_cast<float4 *>(row + 8 * blk) = ea;
-                *reinterpret_cast<float4 *>(row + 8 * blk + 4) = eb;
-            } else if (blk >= 128) {
-                float *r = row + 8 * (blk - 128);
-                *reinterpret_cast<float4 *>(r) = make_float4(ea.x - lo[u][0].x, ea.y - lo[u][0].y, ea.z - lo[u][0].z, ea.w - lo[u][0].w);
-                *reinterpret_cast<float4 *>(r + 4) = make_float4(eb.x - lo[u][1].x, eb.y - lo[u][1].y, eb.z - lo[u][1].z, eb.w - lo[u][1].w);
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { cur[u][0] = nxt[u][0]; cur[u][1] = nxt[u][1]; }
-    }
-#undef AEGIS_CHAIN8
+    };
+    // groups [g0, g1) of one phase; returns with the current samples in `a` again (an odd count is finished through
+    // the mirrored instance)
+    auto run = [&](auto phase, float4 (&a)[8], float4 (&b2)[8], int g0, int g1) {
+        int g = g0;
+        for (; g + 1 < g1; g += 2) { group(phase, a, b2, g); group(phase, b2, a, g + 1); }
+        return g;
+    };
+    using PA = std::integral_constant<int, 0>;
+    using PB = std::integral_constant<int, 1>;
+    using PC = std::integral_constant<int, 2>;
+    // three phases, register roles alternating with every group: a phase of odd length hands over in the other set
+    int g = run(PA{}, ra, rb, 0, nG);
+    bool in_a = true;
+    if (g < nG) { group(PA{}, ra, rb, g); ++g; in_a = false; }
+    if (in_a) { g = run(PB{}, ra, rb, g, 32); if (g < 32) { group(PB{}, ra, rb, g); ++g; in_a = false; } }
+    else      { g = run(PB{}, rb, ra, g, 32); if (g < 32) { group(PB{}, rb, ra, g); ++g; in_a = true; } }
+    if (in_a) { g = run(PC{}, ra, rb, g, 32 + nG); if (g < 32 + nG) group(PC{}, ra, rb, g); }
+    else      { g = run(PC{}, rb, ra, g, 32 + nG); if (g < 32 + nG) group(PC{}, rb, ra, g); }
+#undef AEGIS_CHAIN4
 #undef AEGIS_SQ
 }
 constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1040 * 4 + 128 * 4 + 16 * 4 + 256 * 4;
@@ -215,7 +237,6 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
     float nx[8];
     fetch(geo, nx);
     Fft8Tw twr;
-    if (want_fft) fft8_load_twiddles(twr, tb.twiddle, tid);
 
     // mel: thread t owns chunk t of the filterbank (<= 16 consecutive bins of one triangle) and, for t < n_mels, band t
     const bool has_chunk = want_mel && tid < tb.mel_chunks;
@@ -258,11 +279,9 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             } else {                                         // frames of two clips, or a hop the staging area cannot hold
                 const Geo g = locate(lane);
                 const float *__restrict__ x = p.pcm + g.base;
-                energy_walk<false>([&](int j, float4 &a, float4 &b) {
-                    float v[8];
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) { const int64_t q = g.start + j + i; v[i] = (q >= 0 && q < g.n) ? x[q] : 0.0f; }
-                    a = make_float4(v[0], v[1], v[2], v[3]); b = make_float4(v[4], v[5], v[6], v[7]);
+                energy_walk_plain([&](int j) {
+                    const int64_t q = g.start + j;
+                    return (q >= 0 && q < g.n) ? x[q] : 0.0f;
                 }, row, mp);
             }
         }
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         if (staged) __syncthreads();                     // the staging area becomes the FFT buffer and the frame again
     }
     // (the first barrier of the frame loop publishes the rows)
+    if (want_fft) fft8_load_twiddles(twr, tb.twiddle, tid);      // 40 registers: loaded after the walk, which wants its own
     FRM_TICK(0)
 
     for (int pr = 0; pr < nfr; pr += 2) {
@@ -1009,7 +1029,10 @@ void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
         fpw = kFramesPerWg;
         while (fpw > 2 && kFrameLdsFixed + (size_t)fpw * stride * 4 > 80 * 1024) fpw -= 2;
     }
-    const size_t lds = kFrameLdsFixed + (size_t)fpw * stride * 4;
+    size_t lds = kFrameLdsFixed + (size_t)fpw * stride * 4;
+    // AEGIS_FRAME_LDS_MIN=<bytes> (experiment knob): ask for at least that much LDS, e.g. 100000 keeps one workgroup per CU
+    static const size_t lds_min = [] { const char *e = std::getenv("AEGIS_FRAME_LDS_MIN"); return e ? (size_t)std::atol(e) : (size_t)0; }();
+    lds = std::max(lds, std::min<size_t>(lds_min, 160 * 1024));
     hipLaunchKernelGGL(frame_yin_kernel, dim3((unsigned)((p.n_sel + fpw - 1) / fpw)), dim3(256), lds, s, p, t, fpw, stride);
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
