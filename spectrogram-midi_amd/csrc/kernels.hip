@@ -49,6 +49,21 @@ __device__ __forceinline__ void map_frame(const PassParams &p, int64_t fs, int &
 // frame t of clip c in the output arrays
 __device__ __forceinline__ int64_t out_index(const PassParams &p, int c, int64_t t) { return p.out_off[c] + t; }
 
+// wave maximum of unsigned values, one v_max_u32_dpp per level (0, the identity, stands in for lanes without a source)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned dpp_umax(unsigned v) {
+    return max(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ unsigned wave_umax(unsigned v) {   // uniform result
+    v = dpp_umax<0x111, 0xf>(v);   // row_shr:1
+    v = dpp_umax<0x112, 0xf>(v);   // row_shr:2
+    v = dpp_umax<0x114, 0xf>(v);   // row_shr:4
+    v = dpp_umax<0x118, 0xf>(v);   // row_shr:8
+    v = dpp_umax<0x142, 0xa>(v);   // row_bcast:15
+    v = dpp_umax<0x143, 0xc>(v);   // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Kernel 1: frame stage.  A 256-thread workgroup owns `frames_per_wg` consecutive selected frames (16 in batch
@@ -367,6 +382,12 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 p.out_rms[fo] = sqrtf(total / 2048.0f);
             }
             if (!want_fft) continue;
+            // this thread's 16 filterbank weights: requested here, used after the power spectrum is complete
+            float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
+            if (has_chunk) {
+                const float4 *wp = reinterpret_cast<const float4 *>(tb.mel_chunk_w) + tid * 4;
+                w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; w3 = wp[3];
+            }
 
             // ---- A[k] = FFT(x)[k], B[k] = FFT(b)[k] from Z by symmetry; P = A*B; windowed power from A ----------
             auto Aof = [&](int k) {                  // k taken modulo 2048: A[-1] = conj(A[1]), A[1025] = conj(A[1023])
@@ -397,8 +418,6 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             // ---- mel projection: sparse Slaney triangles.  Every <= 16-bin chunk of a triangle is one thread's float32
             // fma chain; a band then adds its chunks' sums in order (the widest band has six).  Clip maximum.
             if (has_chunk) {
-                const float4 *wp = reinterpret_cast<const float4 *>(tb.mel_chunk_w) + tid * 4;
-                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
                 const float *pp = pw + mel_bin;
                 float acc = 0.0f;
                 acc = fmaf(w0.x, pp[0], acc); acc = fmaf(w0.y, pp[1], acc); acc = fmaf(w0.z, pp[2], acc); acc = fmaf(w0.w, pp[3], acc);
@@ -414,10 +433,9 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                     for (int cidx = band_c0; cidx < band_c1; ++cidx) acc = (cidx == band_c0) ? part[cidx] : acc + part[cidx];
                     p.melpow[f * p.n_mels + tid] = acc;
                 }
-                float m = acc;                       // powers are >= 0: float order == unsigned order of the bits
-#pragma unroll
-                for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                if (lane == 0 && live) atomicMax(&p.clipmax[c], __float_as_uint(m));
+                // powers are >= 0: float order == unsigned order of the bits
+                const unsigned m = wave_umax(__float_as_uint(acc));
+                if (lane == 0 && live) atomicMax(&p.clipmax[c], m);
             }
             FRM_TICK(4)
         }
@@ -521,7 +539,7 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__global__ __launch_bounds__(512) void pyin_obs_kernel(PassParams p, DevTables tb, int frames_per_wave) {
+__global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTables tb, int frames_per_wave) {
     // dynamic LDS: bfact[KM+1] | bexp[KM+1] | bcum[101] (shared), then per wave y[YN] (CMND, reused as the output row) | U,
     // where U holds first the difference function dd[DN] and later, once the CMND is formed, the trough arrays th[KM],
     // tp[KM], ti[KM], tbin[KM]
@@ -529,8 +547,8 @@ __global__ __launch_bounds__(512) void pyin_obs_kernel(PassParams p, DevTables t
     const int nl = p.n_lags, B = p.n_bins;
     const int KM = nl / 2 + 2;
     const int YN = (max(nl, B) + 1) & ~1;
-    const int DN = (p.max_period + 1 + 24 + 1) & ~1;      // + look-ahead of the cumsum walk
-    const int UN = max(DN, 2 * KM + (4 * KM + 7) / 8);    // doubles
+    const int DN = (p.max_period + 1 + 32 + 1) & ~1;      // + look-ahead of the cumsum walk
+    const int UN = (max(DN, 2 * KM + (4 * KM + 7) / 8) + 1) & ~1;    // doubles, even: every wave's arrays start on 16 bytes
     const int TN = (2 * (KM + 1) + 101 + 1) & ~1;
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = (int)(blockDim.x >> 6);
@@ -551,15 +569,17 @@ __global__ __launch_bounds__(512) void pyin_obs_kernel(PassParams p, DevTables t
     for (int i = threadIdx.x; i <= 100; i += blockDim.x) bcum[i] = tb.beta_cumsum[i];
     __syncthreads();
 
-    for (int it = 0; it < frames_per_wave; ++it) {
+    int64_t f = 0, fo = 0, sel_end = 0;                   // the wave's frames are normally consecutive frames of one clip:
+    for (int it = 0; it < frames_per_wave; ++it) {        // the binary search of map_frame runs once, not per frame
     const int64_t fsel = ((int64_t)blockIdx.x * nwaves + wid) * frames_per_wave + it;
     if (fsel >= geo_n_sel(p)) break;                      // wave-uniform
-    int64_t f, fo;
-    {
+    if (it > 0 && fsel < sel_end) { ++f; ++fo; }
+    else {
         int c;
         int64_t t;
         map_frame(p, fsel, c, t, f);
         fo = out_index(p, c, t);
+        sel_end = p.sel_off[c + 1];
     }
     // Cumulative-mean-normalised difference (pitch.py::_cumulative_mean_normalized_difference) from the difference
     // function the frame stage left in HBM: yin[tau] = d[tau] / (cumsum(d[1:])[tau] / tau + tiny).  np.cumsum is strictly
@@ -571,36 +591,37 @@ __global__ __launch_bounds__(512) void pyin_obs_kernel(PassParams p, DevTables t
     for (int i = lane; i <= mp; i += 64) dd[i] = dr[i];
     wave_sync();
     if (lane == 0) {
-        // Straight-line blocks of 8 lags, the next block's values fetched while the current block's dependent adds
-        // run: the walk is bound by the add latency, not by an LDS round trip (or a branch) per lag.  dd is padded,
-        // so the look-ahead reads stay inside the array.
+        // Straight-line groups of 8 lags over two register sets: a group's values are requested (16-byte reads) while
+        // the group before it is chained, so the walk costs its dependent adds and little else -- every instruction
+        // here takes a whole issue slot for one lane's work.  dd is padded: the look-ahead stays inside the array.
         double cs = dd[1];
         if (minp <= 1) y[1 - minp] = cs;
         int tau = 2;
-        double cur[8], nxt[8];
+        constexpr int GL = 8;                 // lags per group (two sets of GL doubles stay in registers)
+        double2 ra[GL / 2], rb[GL / 2];
+        auto request = [&](double2 (&r)[GL / 2], int t0) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = dd[tau + i];
-        for (; tau + 7 < minp; tau += 8) {               // lags below min_period: no CMND value wanted
+            for (int i = 0; i < GL / 2; ++i) r[i] = *reinterpret_cast<const double2 *>(dd + t0 + 2 * i);
+        };
+        auto group = [&](auto all_tag, double2 (&cur)[GL / 2], double2 (&nxt)[GL / 2], int t0) {
+            constexpr bool ALL = decltype(all_tag)::value;       // every lag of the group is >= min_period
+            request(nxt, t0 + GL);
+            double *yo = y + (t0 - minp);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) nxt[i] = dd[tau + 8 + i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cs = cs + cur[i];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+            for (int i = 0; i < GL / 2; ++i) {
+                cs = cs + cur[i].x; if (ALL || t0 + 2 * i >= minp) yo[2 * i] = cs;
+                cs = cs + cur[i].y; if (ALL || t0 + 2 * i + 1 >= minp) yo[2 * i + 1] = cs;
+            }
+        };
+        request(ra, tau);
+        bool in_a = true;
+        for (; tau < minp && tau + GL - 1 <= mp; tau += GL, in_a = !in_a) {   // groups that start below min_period (few)
+            if (in_a) group(std::false_type{}, ra, rb, tau); else group(std::false_type{}, rb, ra, tau);
         }
-        for (; tau < minp && tau <= mp; ++tau) cs = cs + dd[tau];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) cur[i] = dd[tau + i];
-        for (; tau + 7 <= mp; tau += 8) {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) nxt[i] = dd[tau + 8 + i];
-            double *yo = y + (tau - minp);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) { cs = cs + cur[i]; yo[i] = cs; }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
-        }
-        for (; tau <= mp; ++tau) { cs = cs + dd[tau]; y[tau - minp] = cs; }
+        if (!in_a && tau + GL - 1 <= mp) { group(std::true_type{}, rb, ra, tau); tau += GL; }
+        for (; tau + 2 * GL - 1 <= mp; tau += 2 * GL) { group(std::true_type{}, ra, rb, tau); group(std::true_type{}, rb, ra, tau + GL); }
+        if (tau + GL - 1 <= mp) { group(std::true_type{}, ra, rb, tau); tau += GL; }
+        for (; tau <= mp; ++tau) { cs = cs + dd[tau]; if (tau >= minp) y[tau - minp] = cs; }
     }
     wave_sync();
     for (int i = lane; i < nl; i += 64) {
@@ -1037,8 +1058,8 @@ void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
 }
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0) return;
-    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1, DN = (p.max_period + 1 + 24 + 1) & ~1;
-    const int UN = std::max(DN, 2 * KM + (4 * KM + 7) / 8), TN = (2 * (KM + 1) + 101 + 1) & ~1;
+    const int KM = p.n_lags / 2 + 2, YN = (std::max(p.n_lags, p.n_bins) + 1) & ~1, DN = (p.max_period + 1 + 32 + 1) & ~1;
+    const int UN = (std::max(DN, 2 * KM + (4 * KM + 7) / 8) + 1) & ~1, TN = (2 * (KM + 1) + 101 + 1) & ~1;
     // eight waves share one copy of the tables (two such workgroups per CU); small launches (streaming pushes) get a wave
     // per frame and one frame per wave
     int waves = (int)std::min<int64_t>(8, p.n_sel);
