@@ -458,7 +458,9 @@ def main():
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds / launches),
                          "traffic_per_launch": None if traffic is None else int(traffic / launches),
                          # why the HBM fraction is small: the time-sequential Viterbi occupies one CU per clip
-                         "cus_busy_fraction": round(clips_in_flight / N_CUS, 4) if dom == "viterbi" else 1.0,
+                         # (up to 64 clips the library partitions the CUs: 64 for the Viterbi, 192 for the frame stage)
+                         "cus_busy_fraction": round(clips_in_flight / N_CUS, 4) if dom == "viterbi"
+                                              else (0.75 if len(clip_ids) <= 64 else 1.0),
                          "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}},
             "voiced_fraction": round(voiced, 4),
             "rank_busy_ms": rank_busy_ms, "rank_audio_seconds": rank_audio,

@@ -4,10 +4,10 @@ set -o pipefail
 cd /root/repo
 O=/root/repo/gpurun_out/r2prof; mkdir -p $O
 export TMPDIR=/tmp
-timeout -k 10 300 python -m pytest tests/test_gpu_cqt.py tests/test_golden_v1_events.py tests/test_bench_launcher.py -m gpu -x -q > $O/newtests.log 2>&1; echo "new gpu tests rc=$?"; tail -3 $O/newtests.log
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; echo "gpu tests rc=$?"; tail -3 $O/gputests.log
 timeout -k 10 300 python bench.py --steps 10 --warmup 3 > $O/bench_headline.json 2> $O/bench_headline.err; echo "headline rc=$?"; cut -c1-400 $O/bench_headline.json
 timeout -k 10 300 python bench.py --config cqt --steps 5 --warmup 2 > $O/bench_cqt.json 2> $O/bench_cqt.err; echo "cqt rc=$?"; cut -c1-1500 $O/bench_cqt.json
-timeout -k 10 400 python bench.py --config folder --steps 2 --warmup 1 --pass-frames 8400000 --no-cpu-baseline > $O/bench_folder.json 2> $O/bench_folder.err; echo "folder rc=$?"; cut -c1-300 $O/bench_folder.json
+timeout -k 10 400 python bench.py --config folder --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_folder.json 2> $O/bench_folder.err; echo "folder rc=$?"; cut -c1-300 $O/bench_folder.json
 timeout -k 10 300 python bench.py --clips 256 --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_256.json 2> $O/bench_256.err; echo "256 rc=$?"; cut -c1-300 $O/bench_256.json
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o b -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1; echo "prof bench rc=$?"
