@@ -35,7 +35,7 @@ struct DevBuf {
 };
 
 struct PassMeta {   // host copies kept alive until the stream has consumed them
-    std::vector<int64_t> sample_off, sample_len, out_off, frame_off, chunk_off, sel_off;
+    std::vector<int64_t> sample_off, sample_len, out_off, frame_off, chunk_off, sel_off, chunk_lo;
     std::vector<int32_t> order;
 };
 
@@ -68,10 +68,14 @@ struct aegis_handle {
     // Viterbi of the previous one
     struct Work {
         DevBuf dfn, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
-        DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate;
+        DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate, chunk_lo, chunk_flag;
     } work[2];
     int last_work = 0;
-    DevBuf vstats, rk_raw;
+    DevBuf vstats, rk_raw, abort_flag;
+    uint32_t chunk_gen = 0;                   // generation of the chunk flags of a persistent Viterbi launch
+    int test_drop_signal = -1;
+    bool persist_pending = false;             // a persistent launch ran since the abort flag was last read
+    bool persistent = true;                   // one Viterbi launch per balanced pass (AEGIS_VITERBI_PERSISTENT=0: one per chunk)
     CqtBank cqt_bank;
     DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
@@ -272,6 +276,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
+    if (const char *e = std::getenv("AEGIS_VITERBI_PERSISTENT")) h->persistent = std::atoi(e) != 0;
+    if (const char *e = std::getenv("AEGIS_TEST_DROP_CHUNK_SIGNAL")) h->test_drop_signal = std::atoi(e);
     if (const char *e = std::getenv("AEGIS_RAMP_K")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 64) h->ramp_k = (int)v; }
     if (const char *e = std::getenv("AEGIS_CU_SPLIT")) h->split_limit = std::atoi(e);
     CRTHIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, c.device));
@@ -343,9 +349,9 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (auto &w : h->work)
         for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
                           &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
-                          &w.vstate})
+                          &w.vstate, &w.chunk_lo, &w.chunk_flag})
             free_buf(*b);
-    for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
+    for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb})
         free_buf(*b);
@@ -411,6 +417,20 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
 // its neighbour (measured: Viterbi 77.5 ms beside the frame stage, 67.9 ms with the frame stage confined to 192 CUs;
 // keeping frame workgroups off the Viterbi's own CU alone changed nothing).  While a batch leaves CUs free the pipeline
 // therefore runs on CU-masked streams: the Viterbi on the last V CUs of the mask, the frame stage on the others.
+// After a synchronisation: a persistent Viterbi launch that gave up waiting for its chunk flags says so here.
+static int persistent_check(aegis_handle *h) {
+    if (!h->persist_pending) return AEGIS_OK;
+    h->persist_pending = false;
+    uint32_t aborted = 0;
+    HIPCHK(h, hipMemcpy(&aborted, h->abort_flag.p, 4, hipMemcpyDeviceToHost));
+    if (aborted) {
+        HIPCHK(h, hipMemset(h->abort_flag.p, 0, 4));
+        h->err = "the Viterbi kernel gave up waiting for the frame stage (AEGIS_VITERBI_PERSISTENT=0 launches it per chunk)";
+        return AEGIS_ERR_DEVICE;
+    }
+    return AEGIS_OK;
+}
+
 static aegis_handle::SplitSet *split_streams(aegis_handle *h, int n_clips) {
     if (n_clips > h->split_limit || h->split_limit <= 0) return nullptr;
     if (h->n_cus != 256) return nullptr;      // the masks below are laid out for the 256 CUs of an un-partitioned MI355X
@@ -540,7 +560,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // (64 clips x 180 s: 59.5 -> 55.8 ms; measured worse below 56 clips and on unpartitioned passes).
         const bool balanced = py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
                               h->split_limit > 0 && nc <= h->split_limit && nc <= 128;
-        const int64_t kTimeChunk = balanced ? h->balanced_chunk : h->time_chunk;      // multiple of kViterbiChunk
+        // (a persistent Viterbi launch pays nothing per chunk: half the chunk size, 54.3 -> 52.0 ms)
+        const bool may_persist = balanced && h->persistent;
+        const int64_t kTimeChunk = balanced ? (may_persist ? std::max<int64_t>(kViterbiChunk, h->balanced_chunk / 2 / kViterbiChunk * kViterbiChunk) : h->balanced_chunk) : h->time_chunk;
         std::vector<int64_t> cb{0};
         if (balanced && maxF > 2 * kTimeChunk) {
             for (int64_t b = 1 + kTimeChunk; b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
@@ -604,6 +626,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8);
             ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
             ENS(states, fp * 4); ENS(vstate, (size_t)nc * S * 8);
+            ENS(chunk_lo, (size_t)nk * 8); ENS(chunk_flag, (size_t)nk * 4);
         }
         if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
 #undef ENS
@@ -615,12 +638,26 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipMemcpyAsync(w.order.p, m.order.data(), nc * 4, hipMemcpyHostToDevice, fa));
         HIPCHK(h, hipMemcpyAsync(w.sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, fa));
         if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(w.clipmax.p, 0, nc * 4, fa));
-        if (use_fb) {                    // the metadata precedes the second frame stream's kernels
+        PassParams p = base_params(t);
+        // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
+        // observation kernel, instead of being launched per chunk (40 launches of 45 us each at 64 clips x 180 s, and the
+        // kernel's prologue each time).  It needs the frame stage to run beside it, which the CU partition guarantees.
+        const bool persistent = balanced && ss != nullptr && h->persistent && nk > 1 && viterbi_band_applies(p);
+        if (persistent) {
+            if (!h->abort_flag.p) {
+                if ((rc = ensure(h, h->abort_flag, 4)) != AEGIS_OK) return rc;
+                HIPCHK(h, hipMemsetAsync(h->abort_flag.p, 0, 4, fa));
+            }
+            m.chunk_lo.assign(cb.begin(), cb.end() - 1);
+            HIPCHK(h, hipMemcpyAsync(w.chunk_lo.p, m.chunk_lo.data(), (size_t)nk * 8, hipMemcpyHostToDevice, fa));
+            HIPCHK(h, hipMemsetAsync(w.chunk_flag.p, 0, (size_t)nk * 4, fa));       // generations start at 1
+        }
+        if (use_fb || persistent) {      // the metadata precedes the second frame stream's kernels and the Viterbi
             HIPCHK(h, hipEventRecord(h->sync_events[EV_META], fa));
-            HIPCHK(h, hipStreamWaitEvent(fb, h->sync_events[EV_META], 0));
+            if (use_fb) HIPCHK(h, hipStreamWaitEvent(fb, h->sync_events[EV_META], 0));
+            if (persistent) HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_META], 0));
         }
 
-        PassParams p = base_params(t);
         p.stages = stages;
         p.pcm = d_pcm;
         p.sample_off = static_cast<const int64_t *>(w.sample_off.p);
@@ -652,6 +689,15 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.rake_ratio = rake_sensitivity;
         p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
 
+        if (persistent) {
+            p.chunk_flag = static_cast<const uint32_t *>(w.chunk_flag.p);
+            p.chunk_lo = static_cast<const int64_t *>(w.chunk_lo.p);
+            p.n_chunks = nk;
+            p.chunk_gen = ++h->chunk_gen;
+            if (p.chunk_gen == 0) p.chunk_gen = ++h->chunk_gen;
+            p.abort_flag = static_cast<uint32_t *>(h->abort_flag.p);
+            h->persist_pending = true;
+        }
         for (int k = 0; k < nk; ++k) {
             hipStream_t fs = ((two_fs || k < ramp_k) && (k & 1)) ? fb : fa;
             p.sel_off = static_cast<const int64_t *>(w.sel_off.p) + (size_t)k * (nc + 1);
@@ -682,6 +728,21 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             begin_event(h, "frame", fs); launch_frame(p, h->dt, fs); end_event(h, fs);
             if (py) {
                 begin_event(h, "pyin_obs", fs); launch_pyin_obs(p, h->dt, fs); end_event(h, fs);
+                if (persistent) {
+                    if (k != h->test_drop_signal)      // AEGIS_TEST_DROP_CHUNK_SIGNAL=k: the kernel's bounded wait is tested with it
+                        launch_chunk_signal(static_cast<uint32_t *>(w.chunk_flag.p) + k, p.chunk_gen, fs);
+                    if (k == 0) {        // the one launch, ordered behind chunk 0 (its first column reads frame 0)
+                        HIPCHK(h, hipEventRecord(h->sync_events[EV_CHUNK0], fs));
+                        HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0], 0));
+                        PassParams pv = p;
+                        pv.vt_begin = 0; pv.vt_end = INT64_MAX;
+                        begin_event(h, "viterbi", sv);
+                        hipError_t ve = launch_viterbi(pv, h->dt, t.log_trans_band.data(), sv);
+                        end_event(h, sv);
+                        if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+                    }
+                    continue;
+                }
                 if (sv != fs) {
                     HIPCHK(h, hipEventRecord(h->sync_events[EV_CHUNK0 + k], fs));
                     HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0 + k], 0));
@@ -718,6 +779,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipStreamSynchronize(s));
         h->metas.clear();
         if (h->profiling) collect_events(h);
+        return persistent_check(h);
     }
     return AEGIS_OK;
 }
@@ -764,6 +826,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if (d.S_dB) HIPCHK(h, hipMemcpyAsync(out->S_dB, d.S_dB, (size_t)F * nm * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     h->metas.clear();
+    if ((rc = persistent_check(h)) != AEGIS_OK) return rc;
     if (h->profiling) collect_events(h);
     return AEGIS_OK;
     } catch (...) { return abi_fail(h); }

@@ -70,6 +70,14 @@ struct PassParams {
     int32_t *live_states;        // optional [F]: arg-max state of each column as it is produced (streaming preview)
     const StreamCtl *ctl;        // optional: device-resident t_begin / n_sel / vt_begin / vt_end (graph replay)
     unsigned long long *vstats;  // optional [2]: band Viterbi wave-steps, and how many took the observed-sources-only path
+    // One Viterbi launch per pass beside the time-chunked frame stage (band kernels only): before the first step of time
+    // chunk k the kernel waits until chunk_flag[k] == chunk_gen, which launch_chunk_signal() stores behind the chunk's
+    // observation kernel.  A wait that exceeds its bound sets *abort_flag and ends the kernel.
+    const uint32_t *chunk_flag;  // optional [n_chunks]
+    const int64_t *chunk_lo;     // [n_chunks] first frame of each time chunk (chunk 0 starts at frame 0)
+    int32_t n_chunks;
+    uint32_t chunk_gen;
+    uint32_t *abort_flag;
     // workspace (strides in elements)
     double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period
     double *yin;   int32_t yin_stride;   // optional [F][yin_stride]: CMND for lags min..max, written only for the stage tests
@@ -95,6 +103,8 @@ constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
+bool viterbi_band_applies(const PassParams &p);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry
+void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s);
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_finalize_mel(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, int min_frames, int max_frames,

@@ -847,7 +847,7 @@ __global__ __launch_bounds__(256) void decode_kernel(PassParams p, DevTables tb)
     const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (f >= p.n_frames) return;
     const int s = p.states[f];
-    const bool voiced = s < p.n_bins;
+    const bool voiced = (unsigned)s < (unsigned)p.n_bins;      // anything else decodes as unvoiced
     const int c = find_clip(p.frame_off, p.n_clips, f);
     const int64_t fo = out_index(p, c, f - p.frame_off[c]);
     if (p.out_voiced != nullptr) p.out_voiced[fo] = voiced ? 1 : 0;

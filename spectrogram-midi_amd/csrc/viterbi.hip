@@ -387,6 +387,54 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int nch = (T - 1 + C - 1) / C;
     __syncthreads();
 
+    // Persistent launch: the steps are run chunk by chunk, each run after the chunk's observations are in memory.  Lane 0
+    // of the workgroup polls the chunk's flag (agent-scope acquire: the producer ran on other CUs, possibly behind another
+    // XCD's L2), sleeping between polls, and publishes the run's last step through LDS; the workgroup barrier behind it
+    // orders every wave's loads after the acquire.  The poll is bounded: a wait that long means the frame stage is not
+    // running beside this kernel, and the kernel must end rather than hold its CU.  Everything the wait needs is parked
+    // in LDS (the spare doubles behind the wave maxima), so the step loop carries one flag for it, no pointers.
+    const bool chunked = __builtin_amdgcn_readfirstlane(p.chunk_flag != nullptr ? 1 : 0) != 0;
+    volatile int *wslot = reinterpret_cast<volatile int *>(rv + 32);                     // [0] end of run (-1: give up), [1] chunk
+    volatile unsigned long long *wpar = reinterpret_cast<volatile unsigned long long *>(rv + 34);
+    if (chunked && tid == 0) {
+        wpar[0] = reinterpret_cast<unsigned long long>(p.chunk_flag);
+        wpar[1] = reinterpret_cast<unsigned long long>(p.chunk_lo);
+        wpar[2] = reinterpret_cast<unsigned long long>(p.abort_flag);
+        wpar[3] = ((unsigned long long)(unsigned)p.n_chunks << 32) | p.chunk_gen;
+        wslot[1] = 0;
+    }
+    // returns the step the run that starts at step t0 ends before (at most t_stop), or -1
+    auto next_run = [&](int t0, int t_stop) {
+        if (tid == 0) {
+            const uint32_t *flag = reinterpret_cast<const uint32_t *>(wpar[0]);
+            const int64_t *lo = reinterpret_cast<const int64_t *>(wpar[1]);
+            const int n = (int)(wpar[3] >> 32);
+            const uint32_t gen = (uint32_t)wpar[3];
+            int k = wslot[1];
+            while (k + 1 < n && lo[k + 1] <= t0) ++k;                   // the chunk of step t0
+            int end = t_stop;
+            if (k + 1 < n && lo[k + 1] < (int64_t)end) end = (int)lo[k + 1];
+            unsigned spins = 0;
+            const unsigned long long w0 = wall_clock64();                // 100 MHz
+#pragma nounroll
+            while (__hip_atomic_load(flag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
+                __builtin_amdgcn_s_sleep(32);
+                if ((++spins & 1023u) == 0 && wall_clock64() - w0 > 150000000ull) {       // 1.5 s
+                    __hip_atomic_store(reinterpret_cast<uint32_t *>(wpar[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    end = -1;
+                    break;
+                }
+            }
+            wslot[1] = k;
+            wslot[0] = end;
+        }
+        __syncthreads();
+        const int end = wslot[0];
+        __syncthreads();                  // the slot may be written again only after every wave has read it
+        return end;
+    };
+    // (the launch itself is ordered behind chunk 0's observations: the first column reads frame 0)
+
     // this lane's slot inside a parity block
     const int sidx = (is_low || is_high) ? 2 * PADB + vp * 2 * H + eidx : vp * PADB + b2c + H;
     auto store_value = [&](int buf, double v) { val[buf * PB + sidx] = v; };
@@ -482,7 +530,19 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     }
     int ph = 0;               // step parity: columns, origin maps and list slots all alternate with it
     int n_list = 0;           // wave-steps that took the observed-sources-only path (wave-uniform)
-    for (int t = t_lo; t < t_hi; ++t) {
+    // The steps of this launch, cut at the time-chunk boundaries when the launch spans several chunks (persistent
+    // launch): the wait sits between two runs of the step loop, not inside it.
+    int t = t_lo;
+    while (t < t_hi) {
+    int t_end = t_hi;
+    if (chunked) {
+        t_end = next_run(t, t_hi);
+        if (t_end < 0) {                  // gave up: leave a decodable path (all unvoiced) behind, the call reports the error
+            for (int i = tid; i < T; i += nthr) states[i] = B;
+            return;
+        }
+    }
+    for (; t < t_end; ++t) {
         VIT_TICK(5)
         // every lane loads (lanes without a state read bin 0): the sum below then needs no wait at a control-flow join
         const double lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
@@ -754,6 +814,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         ph ^= 1;
         VIT_TICK(4)
     }
+    }   // runs between chunk boundaries
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
     if (blockIdx.x == 0 && lane == 0) {
         for (int k = 0; k < 6; ++k) atomicAdd((unsigned long long *)&g_vit_dbg[wid * 8 + k], (unsigned long long)tacc[k]);
@@ -834,11 +895,26 @@ static size_t viterbi_launch_lds(size_t need, int n_clips) {
     return n_clips <= limit ? std::max<size_t>(need, 160 * 1024) : need;
 }
 
+__global__ void chunk_signal_kernel(uint32_t *flag, uint32_t gen) {
+    __hip_atomic_store(flag, gen, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s) {
+    hipLaunchKernelGGL(chunk_signal_kernel, dim3(1), dim3(1), 0, s, flag, gen);
+}
+
+static bool band_geometry(const PassParams &p) {
+    const int BP = (p.n_bins + 63) & ~63;
+    return p.n_cls == p.width && 2 * BP <= 1024 && p.n_bins >= 4 * p.half_width + 128;
+}
+bool viterbi_band_applies(const PassParams &p) {
+    return band_geometry(p) && p.half_width == 25 && viterbi_band_lds<25>(p, true) <= 160 * 1024;
+}
+
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {
     if (p.n_clips == 0) return hipSuccess;
     const int S = 2 * p.n_bins;
     const int BP = (p.n_bins + 63) & ~63;
-    if (p.n_cls == p.width && 2 * BP <= 1024 && p.n_bins >= 4 * p.half_width + 128) {
+    if (band_geometry(p)) {
         // band-specialised kernels for the two hop/sr ratios the reference uses (44.1k and 22.05k at hop 512)
         if (p.half_width == 25 && viterbi_band_lds<25>(p, true) <= 160 * 1024) {
             BandLT<25> blt;

@@ -280,23 +280,71 @@ def test_two_frame_streams_large_batch(monkeypatch):
     h.close(); ref_h.close()
 
 
-def test_balanced_schedule_small_chunks(monkeypatch):
-    """Passes of 56..64 clips on the CU-partitioned streams run on equal chunks alternating over two frame streams
-    (aegis_api.hip, "balanced passes").  With AEGIS_BALANCED_CHUNK=32 a batch of 60 short ragged clips (one empty)
-    takes that schedule through dozens of chunk hand-overs; a handle with the schedule switched off analyses the same
-    clips.  Bit-identical."""
-    rng = np.random.default_rng(5)
+def _analyze_on_device(h, clips):
+    """The device-pointer entry (what bench.py times; the only entry that takes the CU-partitioned schedules)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    n = np.array([len(c) for c in clips], np.int64)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    F = int(sum(1 + len(c) // 512 for c in clips))
+    d_pcm = torch.from_numpy(np.concatenate(clips) if len(clips) else np.zeros(0, np.float32)).to(dev)
+    outs = {"f0": torch.empty(F, dtype=torch.float64, device=dev), "voiced_flag": torch.empty(F, dtype=torch.uint8, device=dev),
+            "voiced_prob": torch.empty(F, dtype=torch.float64, device=dev), "rms": torch.empty(F, dtype=torch.float32, device=dev),
+            "rake_mask": torch.empty(F, dtype=torch.uint8, device=dev)}
+    h.analyze_batch_device(d_pcm.data_ptr(), off, {k: v.data_ptr() for k, v in outs.items()}, sync=True)
+    return {k: v.cpu().numpy() for k, v in outs.items()}
+
+
+def _ragged_clips(seed, n):
+    rng = np.random.default_rng(seed)
     base = signals.guitar_clip(8.0, seed=23)
-    clips = [base[o:o + n].copy() for o, n in zip(rng.integers(0, 150000, 60), rng.integers(30000, 190000, 60))]
+    clips = [base[o:o + m].copy() for o, m in zip(rng.integers(0, 150000, n), rng.integers(30000, 190000, n))]
     clips[11] = np.zeros(0, np.float32)
+    return clips
+
+
+def test_balanced_schedule_small_chunks(monkeypatch):
+    """Passes of 56..64 clips on the CU-partitioned streams run on equal chunks alternating over two frame streams, with
+    ONE Viterbi launch that waits for a flag per chunk (aegis_api.hip "balanced passes", viterbi.hip next_run).  60 short
+    ragged clips (one empty) through the device entry with AEGIS_BALANCED_CHUNK=64 (dozens of chunk hand-overs): the
+    persistent launch, one launch per chunk (AEGIS_VITERBI_PERSISTENT=0) and the schedule switched off agree bit for bit,
+    and with the host-buffer entry."""
+    clips = _ragged_clips(5, 60)
     monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "0")
     ref_h = _lib.Handle()
-    ref = ref_h.analyze_batch(clips)
-    monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "32")
+    ref = _analyze_on_device(ref_h, clips)
+    host = ref_h.analyze_batch(clips)
+    np.testing.assert_array_equal(ref["f0"], np.concatenate([r["f0"] for r in host]))
+    np.testing.assert_array_equal(ref["rake_mask"].astype(bool), np.concatenate([r["rake_mask"] for r in host]))
+    for env in ({"AEGIS_BALANCED_CHUNK": "64"}, {"AEGIS_BALANCED_CHUNK": "64", "AEGIS_VITERBI_PERSISTENT": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = _lib.Handle()
+        got = _analyze_on_device(h, clips)
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{env} {k}")
+        got = _analyze_on_device(h, clips)                 # the same handle again: chunk flags of a new generation
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{env} second run {k}")
+        h.close()
+    ref_h.close()
+
+
+def test_persistent_viterbi_gives_up(monkeypatch):
+    """The persistent launch's wait is bounded: with one chunk's flag withheld (test hook) the call comes back with an
+    error instead of hanging, and the handle keeps working."""
+    clips = _ragged_clips(6, 60)
+    monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "64")
+    monkeypatch.setenv("AEGIS_TEST_DROP_CHUNK_SIGNAL", "3")
     h = _lib.Handle()
-    got = h.analyze_batch(clips)
-    monkeypatch.delenv("AEGIS_BALANCED_CHUNK")
-    for i in range(len(clips)):
-        for k in ref[i]:
-            np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"clip {i} {k}")
+    with pytest.raises(_lib.AegisError, match="gave up waiting"):
+        _analyze_on_device(h, clips)
+    monkeypatch.delenv("AEGIS_TEST_DROP_CHUNK_SIGNAL")
+    h.close()
+    h = _lib.Handle()
+    monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "0")
+    ref_h = _lib.Handle()
+    a, b = _analyze_on_device(h, clips), _analyze_on_device(ref_h, clips)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
     h.close(); ref_h.close()
