@@ -197,6 +197,8 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name);
  * Returns the element count available; copies min(count, cap).
  * "viterbi_stats" i64[2] (reading resets; "viterbi_stats_peek" does not): wave-steps of the band Viterbi since the last
  * reset and how many of them took the exact observed-sources-only path (bench.py reports the ratio).
+ * "persistent_fallbacks" i64[1]: calls this handle repeated with one Viterbi launch per time chunk after its single
+ * launch per pass gave up waiting for the frame stage (kernels serialised by a counter-collecting profiler, for one).
  * "throw_bad_alloc" / "throw_length_error" / "throw_runtime_error" / "throw_int": test hooks of the exception barrier
  * (the body throws; the call returns AEGIS_ERR_NOMEM / AEGIS_ERR_DEVICE like any other failure).
  * Profiling builds only (csrc/Makefile EXTRA=-DAEGIS_ABLATE=64|128, -DCQT_ABLATE=8; zeros otherwise):

@@ -74,6 +74,8 @@ struct aegis_handle {
     DevBuf vstats, rk_raw, abort_flag;
     uint32_t chunk_gen = 0;                   // generation of the chunk flags of a persistent Viterbi launch
     int test_drop_signal = -1;
+    bool persist_gave_up = false;
+    int64_t persistent_fallbacks = 0;         // calls repeated with one launch per chunk (aegis_debug_fetch "persistent_fallbacks")
     bool persist_pending = false;             // a persistent launch ran since the abort flag was last read
     bool persistent = true;                   // one Viterbi launch per balanced pass (AEGIS_VITERBI_PERSISTENT=0: one per chunk)
     CqtBank cqt_bank;
@@ -408,7 +410,16 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
     try {
     if (!h) return AEGIS_ERR_INVALID;
     std::lock_guard<std::mutex> lock(h->mu);
-    return analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+    int rc = analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+    if (rc != AEGIS_OK && h->persist_gave_up) {
+        // The single Viterbi launch of a balanced pass found the frame stage not running beside it (a profiler collecting
+        // counters serialises kernels, for one): this handle goes back to one launch per chunk and the call is repeated.
+        h->persist_gave_up = false;
+        h->persistent = false;
+        ++h->persistent_fallbacks;
+        rc = analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+    }
+    return rc;
     } catch (...) { return abi_fail(h); }
 }
 
@@ -426,6 +437,7 @@ static int persistent_check(aegis_handle *h) {
     if (aborted) {
         HIPCHK(h, hipMemset(h->abort_flag.p, 0, 4));
         h->err = "the Viterbi kernel gave up waiting for the frame stage (AEGIS_VITERBI_PERSISTENT=0 launches it per chunk)";
+        h->persist_gave_up = true;
         return AEGIS_ERR_DEVICE;
     }
     return AEGIS_OK;
@@ -561,7 +573,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         const bool balanced = py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
                               h->split_limit > 0 && nc <= h->split_limit && nc <= 128;
         // (a persistent Viterbi launch pays nothing per chunk: half the chunk size, 54.3 -> 52.0 ms)
-        const bool may_persist = balanced && h->persistent;
+        const bool may_persist = balanced && h->persistent && sync;
         const int64_t kTimeChunk = balanced ? (may_persist ? std::max<int64_t>(kViterbiChunk, h->balanced_chunk / 2 / kViterbiChunk * kViterbiChunk) : h->balanced_chunk) : h->time_chunk;
         std::vector<int64_t> cb{0};
         if (balanced && maxF > 2 * kTimeChunk) {
@@ -642,7 +654,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
         // observation kernel, instead of being launched per chunk (40 launches of 45 us each at 64 clips x 180 s, and the
         // kernel's prologue each time).  It needs the frame stage to run beside it, which the CU partition guarantees.
-        const bool persistent = balanced && ss != nullptr && h->persistent && nk > 1 && viterbi_band_applies(p);
+        const bool persistent = balanced && ss != nullptr && h->persistent && sync && nk > 1 && viterbi_band_applies(p);
         if (persistent) {
             if (!h->abort_flag.p) {
                 if ((rc = ensure(h, h->abort_flag, 4)) != AEGIS_OK) return rc;
@@ -1437,6 +1449,10 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     else if (n == "logunv") { src = lw.logunv.p; count = F; }
     else if (n == "states") { src = lw.states.p; count = F; esz = 4; }
     else if (n == "melpow") { src = lw.melpow.p; count = F * h->tab.n_mels; esz = 4; }
+    else if (n == "persistent_fallbacks") {
+        if (dst && cap > 0) *static_cast<int64_t *>(dst) = h->persistent_fallbacks;
+        return 1;
+    }
     else if (n == "viterbi_stats" || n == "viterbi_stats_peek") {      // [wave-steps, observed-sources-only wave-steps]
         if (h->device < 0 || !h->vstats.p) return AEGIS_ERR_INVALID;
         if (dst && cap > 0) {
