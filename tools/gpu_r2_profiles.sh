@@ -12,13 +12,22 @@ timeout -k 10 300 python bench.py --clips 256 --steps 3 --warmup 1 --no-cpu-base
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_bench -o b -- python3 /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1; echo "prof bench rc=$?"
 find /tmp/p_bench -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+# counter collection serialises kernels: the single Viterbi launch of a balanced pass would wait for a frame stage that cannot
+# run beside it (the library falls back by itself after 1.5 s; here it is told up front)
+export AEGIS_VITERBI_PERSISTENT=0
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p_fetch -o f -- python3 /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_fetch.log 2>&1; echo "pmc fetch rc=$?"
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p_write -o w -- python3 /root/repo/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $O/pmc_write.log 2>&1; echo "pmc write rc=$?"
 F=$(find /tmp/p_fetch -name "*counter_collection.csv" | head -1); W=$(find /tmp/p_write -name "*counter_collection.csv" | head -1)
 python3 /root/repo/tools/summarize_pmc.py "$F" "$W" 2 $O/pmc_hbm.json > $O/pmc_summary.log 2>&1; echo "pmc summary rc=$?"; tail -30 $O/pmc_summary.log
+unset AEGIS_VITERBI_PERSISTENT
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_stream -o s -- python3 /root/repo/tools/bench_stream.py 1500 > $O/prof_stream.log 2>&1; echo "prof stream (graph) rc=$?"; grep -a "^{" $O/prof_stream.log | cut -c1-300
 find /tmp/p_stream -name "*kernel_stats.csv" -exec cp {} $O/stream_kernel_stats.csv \;
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_trend -o t -- python3 /root/repo/tools/bench_trend.py > $O/prof_trend.log 2>&1; echo "prof trend rc=$?"; grep -a "^{" $O/prof_trend.log | cut -c1-600
 find /tmp/p_trend -name "*kernel_stats.csv" -exec cp {} $O/trend_kernel_stats.csv \;
 cd /root/repo; python3 tools/bench_stream.py 4000 > $O/stream_latency.json 2>&1; cat $O/stream_latency.json | cut -c1-300
+AEGIS_HIP_LIB=/root/repo/_ablate/lib_ab64.so timeout -k 10 200 python3 tools/viterbi_cycles.py > $O/viterbi_cycles.txt 2>&1; tail -3 $O/viterbi_cycles.txt
+AEGIS_BALANCED_CHUNK=0 AEGIS_TIME_CHUNK=65536 AEGIS_HIP_LIB=/root/repo/_ablate/lib_ab128.so timeout -k 10 200 python3 tools/frame_cycles.py > $O/frame_cycles.txt 2>&1; tail -3 $O/frame_cycles.txt
+timeout -k 10 120 tools/_build/ubench_walk > $O/ubench_walk.txt 2>&1; cat $O/ubench_walk.txt
+timeout -k 10 300 python3 tools/bench_engine_e2e.py > $O/engine_e2e.json 2>&1; tail -c 600 $O/engine_e2e.json
+timeout -k 10 300 python3 tools/bench_host_path.py > $O/host_path.json 2>&1; tail -c 600 $O/host_path.json
 ls -la $O
