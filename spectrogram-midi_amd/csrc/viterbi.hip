@@ -242,16 +242,22 @@ __device__ __forceinline__ double wave_max_neg(double v, unsigned long long &at)
     const unsigned hi = (unsigned)__double2hiint(v), lo = (unsigned)__double2loint(v);
     const unsigned mh = wave_umin(hi);
     const bool top = hi == mh;
-    const unsigned ml = wave_umin(top ? lo : 0xffffffffu);
-    at = __ballot(top && lo == ml);
+    const unsigned long long tb = __ballot(top);
+    unsigned ml;
+    if ((tb & (tb - 1)) == 0) {            // one lane holds that high word (the usual case): no second reduction
+        ml = (unsigned)__builtin_amdgcn_readlane((int)lo, (int)__ffsll((long long)tb) - 1);
+        at = tb;
+    } else {
+        ml = wave_umin(top ? lo : 0xffffffffu);
+        at = __ballot(top && lo == ml);
+    }
     return __hiloint2double((int)mh, (int)ml);
 }
-// smallest value among the lanes with take set (finite values; at least one lane takes part)
-__device__ __forceinline__ double wave_min_neg(double v, bool take) {
-    const unsigned hi = take ? (unsigned)__double2hiint(v) : 0u, lo = (unsigned)__double2loint(v);
-    const unsigned mh = wave_umax(hi);
-    const unsigned ml = wave_umax((take && hi == mh) ? lo : 0u);
-    return __hiloint2double((int)mh, (int)ml);
+// a lower bound, within 2^-20 relative, of the smallest value among the lanes with take set (finite negative values; at
+// least one lane takes part): the largest high word with all low bits set.  The list prune only needs a bound.
+__device__ __forceinline__ double wave_min_bound_neg(double v, bool take) {
+    const unsigned hi = take ? (unsigned)__double2hiint(v) : 0u;
+    return __hiloint2double((int)wave_umax(hi), -1);
 }
 // v_min_f64 as one instruction: fmin() first canonicalises an operand that comes straight from memory (a second
 // instruction); the operands here are never NaN.
@@ -494,10 +500,16 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         }
         const unsigned mh = (unsigned)__builtin_amdgcn_readlane((int)row16_umin(ah), 15);
         const bool top = ah == mh;
-        const unsigned ml = (unsigned)__builtin_amdgcn_readlane((int)row16_umin(top ? al : 0xffffffffu), 15);
+        unsigned long long eq2 = __ballot(top) & 0xffffull;                       // waves are in state order
+        unsigned ml;
+        if ((eq2 & (eq2 - 1)) == 0) {
+            ml = (unsigned)__builtin_amdgcn_readlane((int)al, (int)__ffsll((long long)eq2) - 1);
+        } else {
+            ml = (unsigned)__builtin_amdgcn_readlane((int)row16_umin(top ? al : 0xffffffffu), 15);
+            eq2 = __ballot(top && al == ml) & 0xffffull;
+        }
         Gp = G;
         G = __hiloint2double((int)mh, (int)ml);
-        const unsigned long long eq2 = __ballot(top && al == ml) & 0xffffull;     // waves are in state order
         kg = __builtin_amdgcn_readlane(ai, (int)__ffsll((long long)eq2) - 1);
     };
     end_of_step(myv, observed, 0);
@@ -716,7 +728,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             // lookup, add, compare, select -- is skipped on a scalar test.  94 % of the entries on the bench clips: most
             // observed bins are sub-harmonic troughs with tiny probabilities.  The test runs on all 64 bins of a mask word
             // at once (each lane holds one bin's value), so only the surviving entries are walked.
-            const double wmin1 = wave_min_neg(best1, act);
+            const double wmin1 = wave_min_bound_neg(best1, act);
             const double lmax0 = blt.lmax[0 * 2 + vp];
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
