@@ -430,7 +430,15 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             if (want_mel && wid < 2) {
                 float acc = 0.0f;
                 if (tid < p.n_mels && live) {
-                    for (int cidx = band_c0; cidx < band_c1; ++cidx) acc = (cidx == band_c0) ? part[cidx] : acc + part[cidx];
+                    // the band's chunk sums added in order; the first six (every band of the default bank has at most
+                    // six) are requested together instead of one LDS round trip per chunk
+                    float pv[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) pv[k] = part[min(band_c0 + k, 255)];
+                    acc = band_c0 < band_c1 ? pv[0] : 0.0f;
+#pragma unroll
+                    for (int k = 1; k < 6; ++k) if (band_c0 + k < band_c1) acc = acc + pv[k];
+                    for (int cidx = band_c0 + 6; cidx < band_c1; ++cidx) acc = acc + part[cidx];
                     p.melpow[f * p.n_mels + tid] = acc;
                 }
                 // powers are >= 0: float order == unsigned order of the bits

@@ -801,9 +801,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         if (best1 > best) { best = best1; bi = B + src1; }
         // the one out-of-band candidate that can win: the previous column's arg-max
         {
-            const int bg = kg >= B ? kg - B : kg;
-            const int dist = bg > b2c ? bg - b2c : b2c - bg;
-            if (dist > H) {
+            const int bg = kg >= B ? kg - B : kg;                       // scalar
+            if ((unsigned)(b2c + (H - bg)) > (unsigned)(2 * H)) {       // |b' - bg| > H in one add and one compare
                 const double cand = G + p.log_tiny;
                 if (cand > best || (cand == best && kg < bi)) { best = cand; bi = kg; }
             }
