@@ -476,12 +476,21 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     // End-of-step bookkeeping, one barrier: block arg-max (lowest index on ties; wave max -> first lane holding it ->
     // one LDS slot per wave -> every wave reduces the <= 16 slots) and one ballot mask per voiced wave marking the
     // observed voiced states.  wp = parity of the slots written (the step that follows reads them).
+    // The column maximum itself is an LDS atomic: every wave's lane 0 takes the unsigned minimum of its wave maximum's bit
+    // pattern (negative values: smaller pattern = larger value) into one of three rotating slots; behind the barrier a wave
+    // reads the slot and finds the first wave whose maximum has that pattern -- no second reduction.  Slot (k + 1) mod 3
+    // is reset during step k: its last readers passed the previous barrier.
+    unsigned long long *gkey = reinterpret_cast<unsigned long long *>(rv + 40);      // [3], in the spare doubles
+    if (tid < 3) gkey[tid] = ~0ull;
+    __syncthreads();
+    int ks = 0;
     auto end_of_step = [&](double v, bool obs, int wp) {
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 2)
         __syncthreads(); G = v; kg = 0; return;
 #endif
         unsigned long long eq;
         const double wm = wave_max_neg(v, eq);
+        const int kn = ks == 2 ? 0 : ks + 1;
         if (!vp) {                     // wave-uniform
             const unsigned long long om = __ballot(obs);
             if (lane == 0) omask[wp * 16 + wid] = om;
@@ -489,28 +498,22 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         if (lane == 0) {
             rv[wp * 16 + wid] = wm;
             ri[wp * 16 + wid] = vp * B + wlo + (int)__ffsll((long long)eq) - 1;
+            atomicMin(gkey + ks, (unsigned long long)__double_as_longlong(wm));
+            if (wid == 0) gkey[kn] = ~0ull;
         }
         __syncthreads();
-        unsigned ah = 0xfff00000u, al = 0u;      // -inf
+        const unsigned long long gk = gkey[ks];
+        unsigned long long ak = ~0ull;
         int ai = 0x7fffffff;
         if (lane < nw) {
-            const double a = rv[wp * 16 + lane];
-            ah = (unsigned)__double2hiint(a); al = (unsigned)__double2loint(a);
+            ak = (unsigned long long)__double_as_longlong(rv[wp * 16 + lane]);
             ai = ri[wp * 16 + lane];
         }
-        const unsigned mh = (unsigned)__builtin_amdgcn_readlane((int)row16_umin(ah), 15);
-        const bool top = ah == mh;
-        unsigned long long eq2 = __ballot(top) & 0xffffull;                       // waves are in state order
-        unsigned ml;
-        if ((eq2 & (eq2 - 1)) == 0) {
-            ml = (unsigned)__builtin_amdgcn_readlane((int)al, (int)__ffsll((long long)eq2) - 1);
-        } else {
-            ml = (unsigned)__builtin_amdgcn_readlane((int)row16_umin(top ? al : 0xffffffffu), 15);
-            eq2 = __ballot(top && al == ml) & 0xffffull;
-        }
+        const unsigned long long eq2 = __ballot(ak == gk) & 0xffffull;           // waves are in state order
         Gp = G;
-        G = __hiloint2double((int)mh, (int)ml);
+        G = __longlong_as_double((long long)gk);
         kg = __builtin_amdgcn_readlane(ai, (int)__ffsll((long long)eq2) - 1);
+        ks = kn;
     };
     end_of_step(myv, observed, 0);
     if (p.live_states != nullptr && tid == 0 && vt_begin == 0) p.live_states[f0] = kg;
