@@ -572,12 +572,20 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // (64 clips x 180 s: 59.5 -> 55.8 ms; measured worse below 56 clips and on unpartitioned passes).
         const bool balanced = py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
                               h->split_limit > 0 && nc <= h->split_limit && nc <= 128;
-        // (a persistent Viterbi launch pays nothing per chunk: half the chunk size, 54.3 -> 52.0 ms)
+        // (a persistent Viterbi launch pays nothing per chunk: half the chunk size, 54.3 -> 52.0 ms).  The size is stated for
+        // 64 clips and scaled so that a chunk's observation kernel is ONE full round of workgroups on the frame stage's
+        // 192 CUs (2 x 192 workgroups of 32 frames = 12 288 frames = 192 steps x 64 clips) and its frame kernel two:
+        // 224 steps instead of 192 leave a sixth of a second round behind (54.1 instead of 50.6 ms).
         const bool may_persist = balanced && h->persistent && sync;
-        const int64_t kTimeChunk = balanced ? (may_persist ? std::max<int64_t>(kViterbiChunk, h->balanced_chunk / 2 / kViterbiChunk * kViterbiChunk) : h->balanced_chunk) : h->time_chunk;
+        int64_t kTimeChunk = h->time_chunk;
+        if (balanced) {
+            const int64_t at64 = may_persist ? h->balanced_chunk / 2 : h->balanced_chunk;
+            kTimeChunk = std::max<int64_t>(kViterbiChunk, at64 * 64 / nc / kViterbiChunk * kViterbiChunk);
+        }
         std::vector<int64_t> cb{0};
         if (balanced && maxF > 2 * kTimeChunk) {
-            for (int64_t b = 1 + kTimeChunk; b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
+            // (chunk 0 holds frame 0 besides its steps: one back-pointer block less keeps it inside the round too)
+            for (int64_t b = 1 + std::max<int64_t>(kViterbiChunk, kTimeChunk - kViterbiChunk); b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
         } else if (py && maxF > kTimeChunk + kTimeChunk / 2) {
             int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
