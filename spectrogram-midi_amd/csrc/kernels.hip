@@ -272,10 +272,37 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         const bool staged = g0.c == gl.c && p.hop == 512 && span + 4 * (span >> 9) <= 10240;
         float *stage = reinterpret_cast<float *>(z);
         if (staged) {                                // sample i sits at i + 4 (i / 512): the lanes' frames start one hop apart,
-            for (int i = tid; i < (int)span; i += 256) {     // the skew puts their 16-byte reads on distinct bank groups
-                const int64_t idx = g0.start + i;
-                const float v = (idx >= 0 && idx < g0.n) ? p.pcm[g0.base + idx] : 0.0f;
-                stage[i + 4 * (i >> 9)] = v * v;              // squared here, by all threads, not inside the serial walk
+            // the skew puts their 16-byte reads on distinct bank groups.  Four samples per thread and request, all of a
+            // thread's (<= 10) requests in flight together: one sample per request and iteration made the staging, not the
+            // walk, two thirds of the prologue (a memory latency per iteration, 38 iterations).
+            const float *__restrict__ x0 = p.pcm + g0.base;
+            const int n4 = (int)(span >> 2);                 // span is a multiple of 4 (hop = 512)
+            float4 sv[10];
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int q = tid + 256 * u;
+                const int64_t idx = g0.start + 4 * (int64_t)q;
+                float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (q < n4) {
+                    if (idx >= 0 && idx + 3 < g0.n) {
+                        v = *reinterpret_cast<const float4 *>(x0 + idx);      // (4-byte aligned is all a global load needs)
+                    } else {                                 // clip edge: librosa's centre padding is zeros
+                        if (idx >= 0 && idx < g0.n) v.x = x0[idx];
+                        if (idx + 1 >= 0 && idx + 1 < g0.n) v.y = x0[idx + 1];
+                        if (idx + 2 >= 0 && idx + 2 < g0.n) v.z = x0[idx + 2];
+                        if (idx + 3 >= 0 && idx + 3 < g0.n) v.w = x0[idx + 3];
+                    }
+                }
+                sv[u] = v;
+            }
+#pragma unroll
+            for (int u = 0; u < 10; ++u) {
+                const int q = tid + 256 * u;
+                if (q < n4) {                                // squared here, by all threads, not inside the serial walk
+                    const int i = 4 * q;
+                    *reinterpret_cast<float4 *>(stage + i + 4 * (i >> 9)) =
+                        make_float4(sv[u].x * sv[u].x, sv[u].y * sv[u].y, sv[u].z * sv[u].z, sv[u].w * sv[u].w);
+                }
             }
             __syncthreads();
         }
