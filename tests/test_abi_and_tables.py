@@ -236,3 +236,46 @@ def test_pass_throughs_forward_to_the_reference_package(tmp_path, monkeypatch):
     assert eng.separate_stems("a.wav", "out") == ("stems", "a.wav", "out")
     for mod in [m for m in sys.modules if m.split(".")[0] == "aegis_engine_core"]:
         sys.modules.pop(mod)          # not monkeypatch.delitem: its teardown would put the stand-ins back
+
+
+def test_representative_interior_rows_decode_like_the_true_matrix(host_handle):
+    """33 of the 391 interior rows of librosa's transition matrix are normalised by a row sum one ulp away from the one
+    the kernels' band table uses (1 056 of 79 764 in-band entries differ, by < 4e-15 in the log).  The decoded path is what
+    leaves the Viterbi: the oracle's dense decoder run with the TRUE matrix and with the matrix rebuilt from the kernels'
+    table must give the same states on pYIN observations of tonal, polyphonic and noisy clips and on random sparse
+    observation sequences (where near-ties are likeliest)."""
+    from spectrogram_midi_amd import signals
+    p = opyin.PyinParams()
+    B, H, S = 441, 25, 882
+    LT_true = np.log(opyin.transition_matrix(p) + opyin.TINY)
+    band = host_handle.table("log_trans_band").reshape(4, 51, 51)
+    cls = lambda b: b if b < H else (b - (B - 1 - 2 * H) if b > B - 1 - H else H)
+    LT_rep = np.full((S, S), np.log(opyin.TINY))
+    for v in range(2):
+        for v2 in range(2):
+            for b in range(B):
+                js = np.arange(max(0, b - H), min(B, b + H + 1))
+                LT_rep[v * B + b, v2 * B + js] = band[v * 2 + v2, cls(b), js - b + H]
+    differing = LT_rep != LT_true
+    assert 0 < differing.sum() <= 4 * 1056 and np.abs(LT_rep - LT_true).max() < 4e-15
+    log_p_init = np.log(np.ones(S) / S + opyin.TINY)
+    seqs = []
+    rng = np.random.default_rng(11)
+    noisy = signals.guitar_clip(6.0, seed=3) + (10 ** (-12 / 20) * rng.standard_normal(6 * 44100)).astype(np.float32)
+    for y in (signals.guitar_clip(8.0, seed=2), signals.polyphonic_clip(6.0, seed=103), noisy):
+        obs = opyin.pyin(y, return_intermediates=True)[3]["obs"]
+        seqs.append(np.log(obs.T + opyin.TINY))
+    for k in range(3):                                       # random sparse rows: a few observed bins, arbitrary masses
+        T = 400
+        obs = np.zeros((T, S))
+        for t in range(T):
+            n = int(rng.integers(0, 12))
+            bins = rng.integers(0, B, n)
+            w = rng.random(n) * rng.random()
+            obs[t, bins] = w / max(w.sum(), 1e-12) * rng.random()
+            obs[t, B:] = max(0.0, 1.0 - obs[t, :B].sum()) / B
+        seqs.append(np.log(obs + opyin.TINY))
+    for lp in seqs:
+        a = opyin.viterbi_states(lp, LT_true, log_p_init)
+        b = opyin.viterbi_states(lp, LT_rep, log_p_init)
+        np.testing.assert_array_equal(a, b)
