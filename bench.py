@@ -470,6 +470,9 @@ def main():
         }
         if vstats is not None and vstats["wave_steps"] > 0:
             line["viterbi_list_only_rate"] = round(vstats["list_only"] / vstats["wave_steps"], 5)
+        # calls the library repeated with one Viterbi launch per time chunk because its single launch per pass found no
+        # frame stage running beside it (0 unless something serialises kernels, e.g. a counter-collecting profiler)
+        line["persistent_fallbacks"] = int(handle.debug_fetch("persistent_fallbacks")[0])
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds, args.cpu_turbo_seconds, args.cpu_turbo_cores)
     finish(line)
