@@ -48,48 +48,76 @@ __device__ __forceinline__ double np_sum_small(F get, int n) {
     return res;
 }
 
-// One lane walks x[lo..hi) in order, `body(i, x[i])` per element, with the samples fetched eight elements ahead:
+// One lane walks x[lo..hi) in order, `body(i, x[i])` per element, with the samples fetched 64 elements ahead:
 // a lane that loads each sample right before using it pays a full memory round trip per element (0.2 us; a
 // 3-minute pitch track took 1.6 ms per filter, the ghost-note filter's 77 k-element density track 17 ms).
 template <typename Body>
 __device__ __forceinline__ void walk_ahead(const double *__restrict__ x, int64_t lo, int64_t hi, Body body) {
-    constexpr int K = 8;
-    double nxt[K];
+    // K values per block (one 64-byte line), D blocks in flight.  A body costs ~30 cycles and a line that misses the caches
+    // ~0.8 us, so one block of look-ahead left the lane waiting for memory seven eighths of the time (122 ns per element on a
+    // single series); eight lines in flight cover it.  The loads are unconditional (index clamped to the last element): a
+    // load under an in-range test ends at a control-flow join, where the compiler waits for EVERYTHING in flight.
+    constexpr int K = 8, D = 8;
+    if (hi <= lo) return;
+    const int64_t last = hi - 1;
+    double q[D][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) nxt[k] = lo + k < hi ? x[lo + k] : 0.0;
-    for (int64_t i0 = lo; i0 < hi; i0 += K) {
-        double cur[K];
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < K; ++k) cur[k] = nxt[k];
+        for (int k = 0; k < K; ++k) q[d][k] = x[min(lo + d * K + k, last)];
+    for (int64_t i0 = lo; i0 < hi; i0 += D * K) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) nxt[k] = i0 + K + k < hi ? x[i0 + K + k] : 0.0;   // in flight under the bodies below
+        for (int d = 0; d < D; ++d) {
+            const int64_t b0 = i0 + d * K;
+            double cur[K];
 #pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (i0 + k < hi) body(i0 + k, cur[k]);
+            for (int k = 0; k < K; ++k) cur[k] = q[d][k];
+#pragma unroll
+            for (int k = 0; k < K; ++k) q[d][k] = x[min(b0 + D * K + k, last)];   // in flight under D blocks of bodies
+            if (b0 + K <= hi) {               // whole block: no test per element
+#pragma unroll
+                for (int k = 0; k < K; ++k) body(b0 + k, cur[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (b0 + k < hi) body(b0 + k, cur[k]);
+            }
+        }
     }
 }
-// the same over three arrays read in lockstep
 template <typename Body>
 __device__ __forceinline__ void walk_ahead3(const double *__restrict__ x, const double *__restrict__ y,
                                             const double *__restrict__ z, int64_t lo, int64_t hi, Body body) {
-    constexpr int K = 4;
-    double nx[K], ny[K], nz[K];
+    constexpr int K = 4, D = 8;
+    if (hi <= lo) return;
+    const int64_t last = hi - 1;
+    double qx[D][K], qy[D][K], qz[D][K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) { const bool in = lo + k < hi; nx[k] = in ? x[lo + k] : 0.0; ny[k] = in ? y[lo + k] : 0.0; nz[k] = in ? z[lo + k] : 0.0; }
-    for (int64_t i0 = lo; i0 < hi; i0 += K) {
-        double cx[K], cy[K], cz[K];
+    for (int d = 0; d < D; ++d)
 #pragma unroll
-        for (int k = 0; k < K; ++k) { cx[k] = nx[k]; cy[k] = ny[k]; cz[k] = nz[k]; }
+        for (int k = 0; k < K; ++k) { const int64_t i = min(lo + d * K + k, last); qx[d][k] = x[i]; qy[d][k] = y[i]; qz[d][k] = z[i]; }
+    for (int64_t i0 = lo; i0 < hi; i0 += D * K) {
 #pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const bool in = i0 + K + k < hi;
-            nx[k] = in ? x[i0 + K + k] : 0.0; ny[k] = in ? y[i0 + K + k] : 0.0; nz[k] = in ? z[i0 + K + k] : 0.0;
+        for (int d = 0; d < D; ++d) {
+            const int64_t b0 = i0 + d * K;
+            double cx[K], cy[K], cz[K];
+#pragma unroll
+            for (int k = 0; k < K; ++k) { cx[k] = qx[d][k]; cy[k] = qy[d][k]; cz[k] = qz[d][k]; }
+#pragma unroll
+            for (int k = 0; k < K; ++k) { const int64_t i = min(b0 + D * K + k, last); qx[d][k] = x[i]; qy[d][k] = y[i]; qz[d][k] = z[i]; }
+            if (b0 + K <= hi) {               // whole block: no test per element
+#pragma unroll
+                for (int k = 0; k < K; ++k) body(b0 + k, cx[k], cy[k], cz[k]);
+            } else {
+#pragma unroll
+                for (int k = 0; k < K; ++k)
+                    if (b0 + k < hi) body(b0 + k, cx[k], cy[k], cz[k]);
+            }
         }
-#pragma unroll
-        for (int k = 0; k < K; ++k)
-            if (i0 + k < hi) body(i0 + k, cx[k], cy[k], cz[k]);
     }
 }
+
+
 
 // ---- a13: simple_moving_average (financial_analysis.py:45-69) -------------------------------
 // np.convolve(nan->0, ones(w)/w, 'same') then NaN restored.
@@ -116,19 +144,20 @@ __device__ void ema_series(const double *__restrict__ x, int64_t n, int span, do
     const double alpha = 2.0 / (double)(span + 1);
     double prev = NAN;
     bool started = false;
+    const double beta = 1 - alpha;
     walk_ahead(x, 0, n, [&](int64_t i, double v) {
-        double e = NAN;
-        if (v == v) {
-            if (!started) { e = v; started = true; }
-            else if (prev != prev) e = v;
-            else e = alpha * v + (1 - alpha) * prev;
-        }
+        // branch-free (selects): a data-dependent branch per element costs more than the recurrence itself on one lane
+        const bool ok = v == v;
+        const double rec = alpha * v + beta * prev;
+        double e = (started && prev == prev) ? rec : v;      // the first valid sample, or the first after a NaN gap, restarts
+        e = ok ? e : NAN;
+        started = started || ok;
         out[i] = e;
         prev = e;
     });
 }
 
-__global__ void ema_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int span,
+__global__ __launch_bounds__(64) void ema_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int span,
                            double *__restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
@@ -161,18 +190,20 @@ __global__ void bollinger_kernel(const double *__restrict__ x, const int64_t *__
 
 // ---- detect_articulation_bollinger state machine (financial_analysis.py:148-197) -------------
 // codes: 0 None, 1 normal, 2 bend, 3 vibrato, 4 noise
-__global__ void articulation_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+__global__ __launch_bounds__(64) void articulation_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
                                     const double *__restrict__ upper, const double *__restrict__ lower,
                                     int8_t *__restrict__ codes) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
     int prev = 0, vib = 0;   // state: 0 normal, 1 above, 2 below
     walk_ahead3(x, upper, lower, off[s], off[s + 1], [&](int64_t i, double v, double up, double lw) {
-        if (v != v) { codes[i] = 0; return; }
+        const bool ok = v == v;                  // a NaN sample writes 0 and leaves the state alone (selects, no branch)
         const int st = v > up ? 1 : (v < lw ? 2 : 0);
-        if (prev != st && prev != 0) ++vib; else vib = 0;
-        codes[i] = vib >= 2 ? 3 : (st == 1 ? 2 : (st == 2 ? 4 : 1));
-        prev = st;
+        const int vib_new = (prev != st && prev != 0) ? vib + 1 : 0;
+        const int code = vib_new >= 2 ? 3 : (st == 1 ? 2 : (st == 2 ? 4 : 1));
+        codes[i] = (int8_t)(ok ? code : 0);
+        vib = ok ? vib_new : vib;
+        prev = ok ? st : prev;
     });
 }
 
@@ -181,7 +212,7 @@ __global__ void articulation_kernel(const double *__restrict__ x, const int64_t 
 // feeds the signal EMA of the same step.  Every value is produced by the operations, in the order, of three separate
 // exponential_moving_average calls (the reference's form), so the outputs are bit-identical to them; the three separate
 // walks plus two element-wise passes of the first version cost 11 ms per call, one lane waiting on global memory.
-__global__ void macd_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int fast,
+__global__ __launch_bounds__(64) void macd_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int fast,
                             int slow, int sig, double *__restrict__ macd, double *__restrict__ signal,
                             double *__restrict__ hist) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,23 +221,23 @@ __global__ void macd_kernel(const double *__restrict__ x, const int64_t *__restr
     const double af = 2.0 / (double)(fast + 1), as = 2.0 / (double)(slow + 1), ag = 2.0 / (double)(sig + 1);
     double pf = NAN, ps = NAN, pg = NAN;
     bool started = false, gstarted = false;
+    const double bf = 1 - af, bs = 1 - as, bg = 1 - ag;
     walk_ahead(x + o, 0, n, [&](int64_t i, double v) {
-        double ef = NAN, es = NAN;
-        if (v == v) {
-            if (!started) { ef = v; es = v; started = true; }
-            else {
-                ef = (pf != pf) ? v : af * v + (1 - af) * pf;
-                es = (ps != ps) ? v : as * v + (1 - as) * ps;
-            }
-        }
+        // the three EMAs of ema_series, branch-free
+        const bool ok = v == v;
+        const double rf = af * v + bf * pf, rs = as * v + bs * ps;
+        double ef = (started && pf == pf) ? rf : v;
+        double es = (started && ps == ps) ? rs : v;
+        ef = ok ? ef : NAN;
+        es = ok ? es : NAN;
+        started = started || ok;
         pf = ef; ps = es;
         const double m = ef - es;
-        double g = NAN;
-        if (m == m) {
-            if (!gstarted) { g = m; gstarted = true; }
-            else if (pg != pg) g = m;
-            else g = ag * m + (1 - ag) * pg;
-        }
+        const bool mok = m == m;
+        const double rg = ag * m + bg * pg;
+        double g = (gstarted && pg == pg) ? rg : m;
+        g = mok ? g : NAN;
+        gstarted = gstarted || mok;
         pg = g;
         macd[o + i] = m;
         signal[o + i] = g;
@@ -237,7 +268,7 @@ __global__ void slides_kernel(const double *__restrict__ macd, const double *__r
 }
 
 // ---- rsi (financial_analysis.py:274-320), Wilder smoothing, one lane per series ---------------
-__global__ void rsi_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int period,
+__global__ __launch_bounds__(64) void rsi_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int period,
                            double *__restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
@@ -279,13 +310,13 @@ __global__ void rsi_kernel(const double *__restrict__ x, const int64_t *__restri
     int64_t i = (int64_t)period + 1;                // element i uses d[i] - d[i-1]
     double nxt[K + 1];
 #pragma unroll
-    for (int k = 0; k <= K; ++k) nxt[k] = i - 1 + k < n ? d[i - 1 + k] : 0.0;
+    for (int k = 0; k <= K; ++k) nxt[k] = d[min(i - 1 + k, n - 1)];      // (clamped, not tested: see walk_ahead)
     for (; i + K <= n; i += K) {
         double cur[K + 1];
 #pragma unroll
         for (int k = 0; k <= K; ++k) cur[k] = nxt[k];
 #pragma unroll
-        for (int k = 0; k <= K; ++k) nxt[k] = i + K - 1 + k < n ? d[i + K - 1 + k] : 0.0;
+        for (int k = 0; k <= K; ++k) nxt[k] = d[min(i + K - 1 + k, n - 1)];
 #pragma unroll
         for (int k = 0; k < K; ++k) step(cur[k + 1] - cur[k], i + k);
     }
@@ -294,15 +325,18 @@ __global__ void rsi_kernel(const double *__restrict__ x, const int64_t *__restri
 
 // ---- a17: Savitzky-Golay on NaN-compacted samples (financial_filters.py:25-59) ----------------
 // pass 1 (one lane per series): compact valid samples, remember their positions
-__global__ void compact_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
+__global__ __launch_bounds__(64) void compact_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series,
                                double *__restrict__ cx, int64_t *__restrict__ cpos, int64_t *__restrict__ ccount) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
     int64_t k = off[s];
-    for (int64_t i = off[s]; i < off[s + 1]; ++i) {
-        const double v = x[i];
-        if (v == v) { cx[k] = v; cpos[k] = i; ++k; }
-    }
+    // every sample is written at the next free slot and the slot is kept only if the sample is valid (no branch; the slot
+    // after the last valid sample may end up holding an invalid one: slots >= count are never read)
+    walk_ahead(x, off[s], off[s + 1], [&](int64_t i, double v) {
+        cx[k] = v;
+        cpos[k] = i;
+        k += (v == v) ? 1 : 0;
+    });
     ccount[s] = k - off[s];
 }
 
@@ -343,24 +377,26 @@ __global__ void savgol_apply_kernel(const int64_t *__restrict__ off, int n_serie
 }
 
 // ---- Kalman (financial_filters.py:62-99) and Holt (:102-141), one lane per series -------------
-__global__ void kalman_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, double q,
+__global__ __launch_bounds__(64) void kalman_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, double q,
                               double r, double *__restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
     double x_est = NAN, p_est = 1.0;
     bool started = false;
     walk_ahead(x, off[s], off[s + 1], [&](int64_t i, double v) {
-        if (v != v) { out[i] = NAN; return; }
-        if (!started) { x_est = v; started = true; }
-        const double x_pred = x_est, p_pred = p_est + q;
+        const bool ok = v == v;                       // a NaN sample leaves the state alone (selects, no branch)
+        const double x_pred = started ? x_est : v, p_pred = p_est + q;
         const double k = p_pred / (p_pred + r);
-        x_est = x_pred + k * (v - x_pred);
-        p_est = (1 - k) * p_pred;
-        out[i] = x_est;
+        const double x_new = x_pred + k * (v - x_pred);
+        const double p_new = (1 - k) * p_pred;
+        out[i] = ok ? x_new : NAN;
+        x_est = ok ? x_new : x_est;
+        p_est = ok ? p_new : p_est;
+        started = started || ok;
     });
 }
 
-__global__ void holt_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, double alpha,
+__global__ __launch_bounds__(64) void holt_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, double alpha,
                             double beta, double *__restrict__ out) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
@@ -376,14 +412,15 @@ __global__ void holt_kernel(const double *__restrict__ x, const int64_t *__restr
         return;
     }
     double level = first, trend = second - first;
+    const double ca = 1 - alpha, cb = 1 - beta;
     walk_ahead(x, lo, hi, [&](int64_t i, double v) {
-        if (v != v) { out[i] = NAN; return; }
+        const bool ok = v == v;                       // a NaN sample leaves the state alone (selects, no branch)
         const double forecast = level + trend;
-        const double level_new = alpha * v + (1 - alpha) * forecast;
-        const double trend_new = beta * (level_new - level) + (1 - beta) * trend;
-        out[i] = level_new;
-        level = level_new;
-        trend = trend_new;
+        const double level_new = alpha * v + ca * forecast;
+        const double trend_new = beta * (level_new - level) + cb * trend;
+        out[i] = ok ? level_new : NAN;
+        level = ok ? level_new : level;
+        trend = ok ? trend_new : trend;
     });
 }
 
