@@ -51,7 +51,7 @@ struct aegis_handle {
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
     int64_t balanced_chunk = 384;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
-    int balanced_min = 56;                    // fewest clips of a balanced pass (AEGIS_BALANCED_MIN)
+    int balanced_min = 16;                    // fewest clips of a balanced pass (AEGIS_BALANCED_MIN)
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
     hipStream_t stream3 = nullptr;            // host->device sample copies of aegis_analyze_batch, chunk by chunk
@@ -565,11 +565,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // back-pointer-map boundary.  Chunks start at a quarter of time_chunk and grow by 1.25x (the frame stage is
         // faster than the Viterbi per column, so the Viterbi stream never waits after the first chunk).
         //
-        // Balanced passes: on the CU-partitioned streams (split_streams) a pass of 56..64 clips keeps the frame stage's 192
-        // CUs as long per column as the Viterbi keeps its 64 (3.3 vs 3.2 us), so neither may wait for the other: chunks
+        // Balanced passes: on the CU-partitioned streams (split_streams) a pass of 64 clips keeps the frame stage's 192
+        // CUs as long per column as the Viterbi keeps its 64 (3.1 us each), so neither may wait for the other: chunks
         // of one small size (growing chunks make the Viterbi wait a quarter of each), alternating over the two frame
-        // streams so that one chunk's FFT kernel overlaps the previous chunk's latency-bound observation kernel
-        // (64 clips x 180 s: 59.5 -> 55.8 ms; measured worse below 56 clips and on unpartitioned passes).
+        // streams so that one chunk's FFT kernel overlaps the previous chunk's latency-bound observation kernel, and ONE
+        // Viterbi launch that waits for a flag per chunk (64 clips x 180 s: 59.5 -> 50.8 ms).  With fewer clips the pass is
+        // Viterbi-bound and the gain is the launches and the head (48 clips: 52.0 -> 50.2 ms, 16: 50.2 -> 50.0, 8: 49.5
+        // -> 49.8), hence the lower limit; unpartitioned passes lose with small chunks.
         const bool balanced = py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
                               h->split_limit > 0 && nc <= h->split_limit && nc <= 128;
         // (a persistent Viterbi launch pays nothing per chunk: half the chunk size, 54.3 -> 52.0 ms).  The size is stated for

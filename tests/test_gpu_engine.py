@@ -304,7 +304,7 @@ def _ragged_clips(seed, n):
 
 
 def test_balanced_schedule_small_chunks(monkeypatch):
-    """Passes of 56..64 clips on the CU-partitioned streams run on equal chunks alternating over two frame streams, with
+    """Passes of 16..64 clips on the CU-partitioned streams run on equal chunks alternating over two frame streams, with
     ONE Viterbi launch that waits for a flag per chunk (aegis_api.hip "balanced passes", viterbi.hip next_run).  60 short
     ragged clips (one empty) through the device entry with AEGIS_BALANCED_CHUNK=64 (dozens of chunk hand-overs): the
     persistent launch, one launch per chunk (AEGIS_VITERBI_PERSISTENT=0) and the schedule switched off agree bit for bit,
