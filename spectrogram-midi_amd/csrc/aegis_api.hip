@@ -51,6 +51,7 @@ struct aegis_handle {
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
     int64_t balanced_chunk = 384;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
+    int64_t balanced_ends = 64;               // first chunk of a balanced pass with a single Viterbi launch, doubling up to the chunk size and mirrored at the end (AEGIS_BALANCED_ENDS, 0 = off)
     int balanced_min = 16;                    // fewest clips of a balanced pass (AEGIS_BALANCED_MIN)
     int64_t time_chunk = 2048;                // Viterbi steps per pipeline chunk (AEGIS_TIME_CHUNK overrides; multiple of 16)
     hipStream_t stream4 = nullptr;            // second frame-stage stream: odd time chunks (their FFTs overlap the even chunks' YIN / observation kernels)
@@ -277,6 +278,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
+    if (const char *e = std::getenv("AEGIS_BALANCED_ENDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->balanced_ends = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
     if (const char *e = std::getenv("AEGIS_VITERBI_PERSISTENT")) h->persistent = std::atoi(e) != 0;
     if (const char *e = std::getenv("AEGIS_TEST_DROP_CHUNK_SIGNAL")) h->test_drop_signal = std::atoi(e);
@@ -587,6 +589,21 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         std::vector<int64_t> cb{0};
         if (balanced && maxF > 2 * kTimeChunk) {
             // (chunk 0 holds frame 0 besides its steps: one back-pointer block less keeps it inside the round too)
+            if (may_persist && h->balanced_ends > 0 && maxF > 8 * kTimeChunk) {
+                // shorter chunks at both ends (the Viterbi starts behind chunk 0 and finishes a chunk after the frame
+                // stage): ends, 2 ends, ... doubling up to the chunk size, mirrored at the end (50.8 -> 50.4 ms)
+                std::vector<int64_t> ramp;
+                for (int64_t sz = std::max<int64_t>(kViterbiChunk, h->balanced_ends / kViterbiChunk * kViterbiChunk); sz < kTimeChunk; sz *= 2) ramp.push_back(sz);
+                int64_t ramp_sum = 0;
+                for (int64_t v : ramp) ramp_sum += v;
+                int64_t b = 1;
+                for (int64_t v : ramp) { b += v; cb.push_back(b); }
+                const int64_t mid_end = maxF - ramp_sum;
+                for (b += kTimeChunk; b + kTimeChunk / 2 < mid_end; b += kTimeChunk) cb.push_back(b);
+                b = cb.back() + ((mid_end - cb.back()) / kViterbiChunk * kViterbiChunk);
+                if (b > cb.back()) cb.push_back(b);
+                for (size_t i = ramp.size(); i-- > 1;) { b += ramp[i]; if (b < maxF) cb.push_back(b); }
+            } else
             for (int64_t b = 1 + std::max<int64_t>(kViterbiChunk, kTimeChunk - kViterbiChunk); b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
         } else if (py && maxF > kTimeChunk + kTimeChunk / 2) {
             int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
