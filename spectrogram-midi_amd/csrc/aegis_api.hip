@@ -580,7 +580,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // 64 clips and scaled so that a chunk's observation kernel is ONE full round of workgroups on the frame stage's
         // 192 CUs (2 x 192 workgroups of 32 frames = 12 288 frames = 192 steps x 64 clips) and its frame kernel two:
         // 224 steps instead of 192 leave a sixth of a second round behind (54.1 instead of 50.6 ms).
-        const bool may_persist = balanced && h->persistent && sync;
+        const bool may_persist = balanced && h->persistent && sync && viterbi_band_applies(base_params(t), h->dt);
         int64_t kTimeChunk = h->time_chunk;
         if (balanced) {
             const int64_t at64 = may_persist ? h->balanced_chunk / 2 : h->balanced_chunk;
@@ -681,7 +681,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
         // observation kernel, instead of being launched per chunk (40 launches of 45 us each at 64 clips x 180 s, and the
         // kernel's prologue each time).  It needs the frame stage to run beside it, which the CU partition guarantees.
-        const bool persistent = balanced && ss != nullptr && h->persistent && sync && nk > 1 && viterbi_band_applies(p);
+        const bool persistent = may_persist && ss != nullptr && nk > 1;
         if (persistent) {
             if (!h->abort_flag.p) {
                 if ((rc = ensure(h, h->abort_flag, 4)) != AEGIS_OK) return rc;

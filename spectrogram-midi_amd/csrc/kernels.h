@@ -103,7 +103,7 @@ constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
-bool viterbi_band_applies(const PassParams &p);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry
+bool viterbi_band_applies(const PassParams &p, const DevTables &t);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry
 void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s);
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_finalize_mel(const PassParams &p, const DevTables &t, hipStream_t s);

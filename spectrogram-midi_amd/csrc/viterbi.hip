@@ -920,8 +920,11 @@ static bool band_geometry(const PassParams &p) {
     const int BP = (p.n_bins + 63) & ~63;
     return p.n_cls == p.width && 2 * BP <= 1024 && p.n_bins >= 4 * p.half_width + 128;
 }
-bool viterbi_band_applies(const PassParams &p) {
-    return band_geometry(p) && p.half_width == 25 && viterbi_band_lds<25>(p, true) <= 160 * 1024;
+bool viterbi_band_applies(const PassParams &p, const DevTables &t) {      // the two branches of launch_viterbi below
+    if (!band_geometry(p)) return false;
+    if (p.half_width == 25) return viterbi_band_lds<25>(p, true) <= 160 * 1024;
+    if (p.half_width == 50) return t.lt_pack != nullptr && viterbi_band_lds<50>(p, true) <= 160 * 1024;
+    return false;
 }
 
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s) {

@@ -320,12 +320,37 @@ def test_balanced_schedule_small_chunks(monkeypatch):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         h = _lib.Handle()
+        h.set_profiling(True)
         got = _analyze_on_device(h, clips)
         for k in ref:
             np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{env} {k}")
+        launches = h.kernel_launches("viterbi")
+        assert (launches == 1) if "AEGIS_VITERBI_PERSISTENT" not in env else (launches > 1)
         got = _analyze_on_device(h, clips)                 # the same handle again: chunk flags of a new generation
         for k in ref:
             np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{env} second run {k}")
+        h.close()
+    ref_h.close()
+
+
+def test_balanced_schedule_at_22050_hz(monkeypatch):
+    """The same schedules at the v2 engine's rate (22 050 Hz: transition width 101, viterbi_band_kernel<50>): single
+    Viterbi launch, one launch per chunk and the schedule switched off agree bit for bit."""
+    clips = _ragged_clips(7, 24)
+    monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "0")
+    ref_h = _lib.Handle(sample_rate=22050)
+    ref = _analyze_on_device(ref_h, clips)
+    for env in ({"AEGIS_BALANCED_CHUNK": "64"}, {"AEGIS_BALANCED_CHUNK": "64", "AEGIS_VITERBI_PERSISTENT": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = _lib.Handle(sample_rate=22050)
+        h.set_profiling(True)
+        got = _analyze_on_device(h, clips)
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{env} {k}")
+        assert int(h.debug_fetch("persistent_fallbacks")[0]) == 0
+        launches = h.kernel_launches("viterbi")
+        assert (launches == 1) if "AEGIS_VITERBI_PERSISTENT" not in env else (launches > 1)
         h.close()
     ref_h.close()
 
