@@ -304,6 +304,11 @@ __device__ long long g_vit_dbg[16 * 8];
 #ifndef AEGIS_VIT_GATE
 #define AEGIS_VIT_GATE 1       // edge rows: reach gates + immediate table offsets (0: compare / select per candidate)
 #endif
+#ifndef AEGIS_VIT_GROUP50
+#define AEGIS_VIT_GROUP50 0    // the same for the 22.05 kHz band (H = 50, 101 candidates): measured slower there in every
+                               // group size (10: 61.0, 13: 60.7, 17: 61.5 ms against 58.4 for the index-tracking chain; the kernel sits
+                               // at the 128-register limit of 14 waves per CU)
+#endif
 #ifndef AEGIS_VIT_GROUP
 #define AEGIS_VIT_GROUP 7      // candidates per group of the unvoiced-source arg-max (0: index-tracking chain)
 #endif
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         constexpr int HALF = (W + 1) / 2;
         double best1;
         int code1;
-#if AEGIS_VIT_GROUP
+        constexpr int GSEL = H > 25 ? AEGIS_VIT_GROUP50 : AEGIS_VIT_GROUP;
+        if constexpr (GSEL != 0) {
         // Arg-max in three phases.  Tracking the index beside the maximum costs four vector instructions per candidate
         // (add, compare, select, max) and the step is bound by vector issue.  Phase 1 takes only the maxima of NG
         // groups of GS consecutive candidates (add, max); phase 2 finds the first group holding the overall maximum;
@@ -630,7 +636,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         // The last group is anchored at W - GS and overlaps its predecessor instead of running past the band: a maximum
         // inside the overlap is found in the earlier group, which phase 2 prefers.
         {
-            constexpr int GS = H > 25 ? 10 : AEGIS_VIT_GROUP, NG = (W + GS - 1) / GS;    // NG maxima stay in registers
+            constexpr int GS = GSEL, NG = (W + GS - 1) / GS;    // NG maxima stay in registers
             double gm[NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
@@ -658,8 +664,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
                 if (cand == best1) code1 = d0 + k;
             }
         }
-#else
-        {
+        } else {
             double best1b = -INFINITY;
             int code1b = 0;
             best1 = -INFINITY;
@@ -677,7 +682,6 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             }
             if (best1b > best1) { best1 = best1b; code1 = code1b; }
         }
-#endif
         int src1 = b2c + code1 - H;
 #if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
         if (wave_low) {     // low-edge sources precede the interior ones in state order: they win ties
