@@ -1493,6 +1493,17 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
         }
         return 2;
     }
+    else if (n == "obs_cycles") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {
+            long long v[16];
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, obs_debug_fetch(v));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
+        }
+        return 16;
+    }
     else if (n == "frame_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;
         if (dst && cap > 0) {

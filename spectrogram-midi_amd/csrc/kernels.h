@@ -112,6 +112,7 @@ void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, 
 void launch_stream_advance(StreamCtl *ctl, const float *staging, int n_push, float *pcm, int hop, hipStream_t s);
 void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *vprob, const int32_t *live, void *result,
                           hipStream_t s);
+hipError_t obs_debug_fetch(long long *dst);                  // pyin_obs_kernel section cycles (AEGIS_ABLATE&256)
 hipError_t frame_debug_fetch(long long *dst);                // frame_yin_kernel section cycles (AEGIS_ABLATE&128)
 hipError_t viterbi_debug_fetch(long long *dst, bool reset);   // per-wave section cycles (zeros unless AEGIS_ABLATE&64)
 hipError_t viterbi_configure();   // raises the dynamic-LDS limits once (all kernels)

@@ -574,6 +574,12 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 256)
+__device__ long long g_obs_dbg[16];
+#define OBS_TICK(k) { const long long now__ = clock64(); oacc[k] += now__ - olast; olast = now__; }
+#else
+#define OBS_TICK(k)
+#endif
 __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTables tb, int frames_per_wave) {
     // dynamic LDS: bfact[KM+1] | bexp[KM+1] | bcum[101] (shared), then per wave y[YN] (CMND, reused as the output row) | U,
     // where U holds first the difference function dd[DN] and later, once the CMND is formed, the trough arrays th[KM],
@@ -599,6 +605,9 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     int16_t *tbin = ti + KM;
     __shared__ double beta_s[104];
 
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 256)
+    long long oacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, olast = clock64();
+#endif
     for (int i = threadIdx.x; i < 100; i += blockDim.x) beta_s[i] = tb.beta_probs[i];
     for (int i = threadIdx.x; i <= KM; i += blockDim.x) { bfact[i] = tb.boltz_fact[i]; bexp[i] = tb.boltz_exp[i]; }
     for (int i = threadIdx.x; i <= 100; i += blockDim.x) bcum[i] = tb.beta_cumsum[i];
@@ -623,8 +632,17 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     const int mp = p.max_period, minp = p.min_period;
     const double *__restrict__ dr = p.dfn + f * (int64_t)p.lag_stride;
     wave_sync();                            // the previous frame's output row has been read out of this wave's buffers
-    for (int i = lane; i <= mp; i += 64) dd[i] = dr[i];
+    // five requests per lane in flight, then their five LDS stores (one request per iteration waited a memory latency
+    // nine times: 13 k of a frame's 88 k cycles; wider batches cost registers this kernel does not have)
+    for (int base = lane; base <= mp; base += 320) {
+        double t5[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) t5[u] = dr[min(base + 64 * u, mp)];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) if (base + 64 * u <= mp) dd[base + 64 * u] = t5[u];
+    }
     wave_sync();
+    OBS_TICK(0)
     if (lane == 0) {
         // Straight-line groups of 8 lags over two register sets: a group's values are requested (16-byte reads) while
         // the group before it is chained, so the walk costs its dependent adds and little else -- every instruction
@@ -659,6 +677,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
         for (; tau <= mp; ++tau) { cs = cs + dd[tau]; if (tau >= minp) y[tau - minp] = cs; }
     }
     wave_sync();
+    OBS_TICK(1)
     for (int i = lane; i < nl; i += 64) {
         const int tau = i + minp;
         y[i] = dd[tau] / (y[i] / (double)tau + DBL_MIN);
@@ -670,6 +689,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     }
     wave_sync();
 
+    OBS_TICK(2)
     // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
     const int CH = (nl + 63) >> 6;
     unsigned mask = 0;
@@ -694,6 +714,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     }
     wave_sync();
 
+    OBS_TICK(3)
     double vp = 0.0;
     const int rounds = (K + 63) >> 6;
     // Everything below is unrolled over the rounds of 64 troughs a frame may need (up to 8); nearly every frame has at
@@ -727,6 +748,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                 }
             }
             jmin = wave_min_i32(jmin);
+            OBS_TICK(4)
 
             // probs[k] = sum_j [h_k < thr_{j+1}] * boltzmann.pmf(pos_k(j); 2, n_j) * beta_probs[j],
             // products added in ascending j (the order the oracle fixes for librosa's BLAS dot).
@@ -768,6 +790,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                 j = nxt;
             }
 
+            OBS_TICK(5)
             // global minimum trough (first index on ties) gets the no-trough mass
             double bh = INFINITY;
             int bk = kKMax;
@@ -817,6 +840,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                 }
             }
         }
+        OBS_TICK(6)
         wave_sync();                 // last read of y is behind us: the buffer becomes the output row
         for (int b = lane; b < B; b += 64) row[b] = p.log_tiny;
         wave_sync();
@@ -865,6 +889,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     if (rounds <= 2) tail(std::integral_constant<int, 2>{});
     else tail(std::integral_constant<int, kMaxRounds>{});
     wave_sync();
+    OBS_TICK(7)
     double *__restrict__ orow = p.logobs + f * (int64_t)p.obs_stride;
     for (int b = lane; b < B; b += 64) orow[b] = row[b];
     if (lane == 0) {
@@ -872,8 +897,17 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
         p.logunv[f] = log(unv + DBL_MIN);
         if (p.out_vprob != nullptr) p.out_vprob[fo] = vp;
     }
+    OBS_TICK(8)
     }   // frames of this wave
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 256)
+    if (blockIdx.x == 100 && threadIdx.x == 0) { for (int k = 0; k < 9; ++k) g_obs_dbg[k] = oacc[k]; g_obs_dbg[9] = frames_per_wave; }
+#endif
 }
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 256)
+hipError_t obs_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_obs_dbg), sizeof(long long) * 16); }
+#else
+hipError_t obs_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Kernel 5a: f0 / voiced decode (pitch.py: f0 = freqs[state % B], voiced = state < B).

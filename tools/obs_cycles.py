@@ -1,0 +1,19 @@
+"""Section cycle counters of pyin_obs_kernel (workgroup 100, wave 0, summed over its frames); needs a -DAEGIS_ABLATE=256 build:
+make -C spectrogram-midi_amd/csrc EXTRA=-DAEGIS_ABLATE=256 OBJDIR=_objab256 OUT=../../_ablate/lib_ab256.so
+AEGIS_BALANCED_CHUNK=0 AEGIS_TIME_CHUNK=65536 AEGIS_HIP_LIB=_ablate/lib_ab256.so python tools/obs_cycles.py"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from spectrogram_midi_amd import _lib, signals
+y = signals.guitar_clip(180.0, seed=1)
+clips = [np.roll(y, 1000 * i) for i in range(64)]
+h = _lib.Handle()
+h.analyze_batch(clips)
+v = h.debug_fetch("obs_cycles")
+names = ["map + difference-function load", "CMND cumsum (one lane)", "quotients", "troughs + compaction", "threshold indices",
+         "change-point prior loop", "minimum trough, parabolic refinement, bins", "row init, winners, voiced_prob", "output row copy"]
+n = max(int(v[9]), 1)
+tot = int(v[:9].sum())
+print(f"wave 0 of workgroup 100: {n} frames, {tot // n} clock64 ticks per frame")
+for name, c in zip(names, v[:9]):
+    print(f"  {name:45s} {int(c) // n:8d}  {100.0 * c / max(tot, 1):5.1f} %")
