@@ -850,19 +850,31 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
             // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
             bool winq[MAXR];
             double prq[MAXR];
+            // the next trough that carries probability, for every trough at once: one ballot per round of 64 troughs and a
+            // per-lane shift instead of a walk over tbin (a data-dependent loop of dependent LDS reads per lane)
+            int binq[MAXR];
+            unsigned long long hasm[MAXR];
     #pragma unroll
             for (int q = 0; q < MAXR; ++q) {
                 const int k = q * 64 + lane;
+                binq[q] = (q < rounds && k < K) ? (int)tbin[k] : -1;
+                hasm[q] = __ballot(binq[q] >= 0);
+            }
+    #pragma unroll
+            for (int q = 0; q < MAXR; ++q) {
                 winq[q] = false; prq[q] = 0.0;
-                if (q < rounds && k < K) {
-                    const int bin = tbin[k];
-                    bool win = false;
-                    if (bin >= 0 && bin < B) {
-                        int k2 = k + 1;
-                        while (k2 < K && tbin[k2] < 0) ++k2;
-                        win = (k2 >= K) || (tbin[k2] != bin);
-                        if (win) { prq[q] = tp[k]; row[bin] = log(prq[q] + DBL_MIN); }
+                const int bin = binq[q];
+                if (bin >= 0 && bin < B) {
+                    const unsigned long long above = lane < 63 ? hasm[q] >> (lane + 1) : 0ull;
+                    int k2 = -1;
+                    if (above) k2 = q * 64 + lane + (int)__ffsll((long long)above);
+                    else {
+    #pragma unroll
+                        for (int q2 = MAXR - 1; q2 > q; --q2)
+                            if (hasm[q2]) k2 = q2 * 64 + (int)__ffsll((long long)hasm[q2]) - 1;
                     }
+                    const bool win = (k2 < 0) || ((int)tbin[k2 < 0 ? 0 : k2] != bin);
+                    if (win) { prq[q] = tp[q * 64 + lane]; row[bin] = log(prq[q] + DBL_MIN); }
                     winq[q] = win;
                 }
             }
