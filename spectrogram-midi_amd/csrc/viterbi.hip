@@ -574,10 +574,9 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         double xw[3];
         unsigned long long mk[3];
 #pragma unroll
-        for (int u = 0; u < 3; ++u) {
-            const bool okw = LT_LDS && lw0 + u <= lw1;
-            mk[u] = okw ? omask[cur * 16 + lw0 + u] : 0ull;
-            xw[u] = okw ? colr[lidx[u]] : -INFINITY;
+        for (int u = 0; u < 3; ++u) {         // unconditional: a word past the reach repeats the last one and is masked out below
+            mk[u] = omask[cur * 16 + min(lw0 + u, lw1)];
+            xw[u] = colr[lidx[u]];
         }
 
         const double *vi0 = colr + b2c;
