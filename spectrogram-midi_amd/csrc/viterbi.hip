@@ -548,6 +548,9 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         if (lw0 + u == lw1) m &= ~0ull >> (63 - (lrhi & 63));
         wmask[u] = m;
     }
+    // this lane's observation of step t: one pointer and one stride for both voicings (no branch in the step)
+    const double *__restrict__ lp_base = vp ? lunv : lobs + b2c;
+    const int lp_stride = vp ? 1 : os;
     int ph = 0;               // step parity: columns, origin maps and list slots all alternate with it
     int n_list = 0;           // wave-steps that took the observed-sources-only path (wave-uniform)
     // The steps of this launch, cut at the time-chunk boundaries when the launch spans several chunks (persistent
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     for (; t < t_end; ++t) {
         VIT_TICK(5)
         // every lane loads (lanes without a state read bin 0): the sum below then needs no wait at a control-flow join
-        const double lp = vp ? lunv[t] : lobs[(int64_t)t * os + b2c];
+        const double lp = lp_base[(int64_t)t * lp_stride];
         const int cur = __builtin_amdgcn_readfirstlane(ph);
         const double *colr = val + cur * PB;        // the column being read
         // observed bins within reach of this wave's targets, [wlo - H, whi + H], span <= 3 mask words: the masks and
