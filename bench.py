@@ -45,7 +45,7 @@ def make_clips(n_clips, seconds, seed0):
     """n_clips distinct synthetic guitar clips.  Eight base clips are synthesised (Karplus-Strong
     notes + rake bursts + noise floor, signals.guitar_clip); the rest are circular shifts of them
     with a different gain, which keeps set-up time bounded without repeating any clip."""
-    from spectrogram_midi_amd import signals
+    from tools import signals
     n_base = min(n_clips, 8)
     base = [signals.guitar_clip(seconds, SR, seed=seed0 + i) for i in range(n_base)]
     rng = np.random.default_rng(seed0)
@@ -71,7 +71,7 @@ def make_folder_clips(indices, durations):
     """The clips `indices` of the folder.  Clip i is cut, at a seeded offset and gain, from one of eight 330 s base
     tracks chosen by i mod 8: six monophonic guitar tracks, one three-voice polyphonic track, one guitar track under a
     -12 dBFS noise floor (where the Viterbi's exact prunes fire least)."""
-    from spectrogram_midi_amd import signals
+    from tools import signals
     kinds = sorted({i % 8 for i in indices})
     base = {}
     for k in kinds:
@@ -104,7 +104,7 @@ def cpu_baseline(sample_seconds, turbo_seconds, turbo_cores):
     import multiprocessing as mp
     from concurrent.futures import ProcessPoolExecutor
     from oracle import engine as oracle_engine
-    from spectrogram_midi_amd import signals
+    from tools import signals
     _turbo_worker_init()
     y = signals.guitar_clip(sample_seconds, SR, seed=1)
     t0 = time.perf_counter()
@@ -211,7 +211,8 @@ def run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum):
     host PCM; `value` comes from the kernel's own HIP-event time (inputs resident in HBM), the host-inclusive wall time
     is reported beside it."""
     import torch
-    from spectrogram_midi_amd import _lib, signals
+    from spectrogram_midi_amd import _lib
+    from tools import signals
     clips = [signals.polyphonic_clip(30.0, SR, seed=100 + 64 * rank + i) for i in range(8)]
     rng = np.random.default_rng(rank)
     while len(clips) < 64:

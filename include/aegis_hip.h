@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define AEGIS_ABI_VERSION 1
+#define AEGIS_ABI_VERSION 2
 
 /* return codes */
 #define AEGIS_OK 0
@@ -40,6 +40,9 @@ extern "C" {
 
 typedef struct aegis_handle aegis_handle;
 
+#define AEGIS_PYIN_INIT_UNVOICED 0
+#define AEGIS_PYIN_INIT_UNIFORM 1
+
 /* Replaces AegisEngine.__init__ (aegis_engine.py:17-20) plus the librosa
  * defaults the reference relies on.  Zero / NaN fields take the default. */
 typedef struct aegis_config {
@@ -51,7 +54,13 @@ typedef struct aegis_config {
     double fmax;                /* pYIN fmax; 0 -> note_to_hz('C6') = 1046.5022612023945 */
     int32_t device;             /* HIP device ordinal; -1 = host tables only (no GPU touched:
                                    aegis_get_table/param work, analyze calls fail with AEGIS_ERR_DEVICE) */
-    int32_t reserved;
+    int32_t pyin_init;          /* initial distribution of the pYIN HMM (librosa core/pitch.py::pyin builds p_init, then
+                                   sequence.viterbi(observation_probs, transition, p_init=p_init)):
+                                   AEGIS_PYIN_INIT_UNVOICED (0, default) = librosa's published code: p_init = zeros(2B),
+                                   p_init[B:] = 1/B -- the chain starts unvoiced, voiced states start at log(0 + tiny);
+                                   AEGIS_PYIN_INIT_UNIFORM (1) = 1/(2B) on every state (SURVEY.md P11's reading, the
+                                   behaviour of ABI version 1).  Every Turbo-Mode chunk (aegis_engine.py:197-210) and
+                                   every clip starts its own chain, so the choice shows in their first frames. */
     int64_t max_frames_per_pass; /* workspace bound; 0 -> default (1<<21 frames, ~15 KB each) */
 } aegis_config;
 
@@ -187,7 +196,7 @@ int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64
 
 /* Scalar parameters derived at create time.  name in {"min_period","max_period",
  * "n_lags","n_pitch_bins","transition_width","n_trans_classes","max_frames_per_pass",
- * "lag_stride","yin_stride","obs_stride","last_frames"}. */
+ * "lag_stride","yin_stride","obs_stride","last_frames","pyin_init"}. */
 int64_t aegis_get_param(const aegis_handle *h, const char *name);
 
 /* Copies an intermediate of the most recent pass (device -> host), for stage-level

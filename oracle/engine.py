@@ -38,22 +38,23 @@ def turbo_chunks(n_samples, sr, hop_length, num_cores):
 
 
 def _chunk_worker(args):
-    chunk, sr, hop = args
-    return _pyin.pyin(chunk, sr=sr, hop_length=hop, fmin=FMIN, fmax=FMAX)
+    chunk, sr, hop = args[:3]
+    p_init = args[3] if len(args) > 3 else "unvoiced"
+    return _pyin.pyin(chunk, sr=sr, hop_length=hop, fmin=FMIN, fmax=FMAX, p_init=p_init)
 
 
-def parallel_pitch_tracking(y, sr=44100, hop_length=512, num_cores=8, pool=None):
-    """aegis_engine.py:183-216 with an explicit core count."""
+def parallel_pitch_tracking(y, sr=44100, hop_length=512, num_cores=8, pool=None, p_init="unvoiced"):
+    """aegis_engine.py:183-216 with an explicit core count (p_init: oracle.pyin.initial_distribution)."""
     if len(y) / sr < 5.0:
-        return _pyin.pyin(y, sr=sr, hop_length=hop_length, fmin=FMIN, fmax=FMAX)
-    args = [(y[lo:hi], sr, hop_length) for lo, hi in turbo_chunks(len(y), sr, hop_length, num_cores)]
+        return _pyin.pyin(y, sr=sr, hop_length=hop_length, fmin=FMIN, fmax=FMAX, p_init=p_init)
+    args = [(y[lo:hi], sr, hop_length, p_init) for lo, hi in turbo_chunks(len(y), sr, hop_length, num_cores)]
     results = list(pool.map(_chunk_worker, args)) if pool is not None else [_chunk_worker(a) for a in args]
     f0s, flags, probs = zip(*results)
     return np.concatenate(f0s), np.concatenate(flags), np.concatenate(probs)
 
 
 def audio_to_midi(y, sr=44100, hop_length=512, n_fft=2048, rake_sensitivity=0.6,
-                  turbo_mode=False, num_cores=8, pool=None):
+                  turbo_mode=False, num_cores=8, pool=None, p_init="unvoiced"):
     """aegis_engine.py:50-75 from decoded PCM onward."""
     y = np.asarray(y, dtype=np.float32)
     if len(y) == 0:
@@ -61,9 +62,9 @@ def audio_to_midi(y, sr=44100, hop_length=512, n_fft=2048, rake_sensitivity=0.6,
     S_dB = load_features(y, sr, hop_length, n_fft)
     rake_mask = rake.detect_rake_patterns(S_dB, hop_length, sr, rake_sensitivity)
     if turbo_mode:
-        f0, voiced_flag, voiced_probs = parallel_pitch_tracking(y, sr, hop_length, num_cores, pool)
+        f0, voiced_flag, voiced_probs = parallel_pitch_tracking(y, sr, hop_length, num_cores, pool, p_init)
     else:
-        f0, voiced_flag, voiced_probs = _pyin.pyin(y, sr=sr, hop_length=hop_length, fmin=FMIN, fmax=FMAX)
+        f0, voiced_flag, voiced_probs = _pyin.pyin(y, sr=sr, hop_length=hop_length, fmin=FMIN, fmax=FMAX, p_init=p_init)
     f0 = np.nan_to_num(f0)
     level = dsp.rms(y, hop_length=hop_length)
     return {"rake_mask": rake_mask, "f0": f0, "voiced_flag": voiced_flag,

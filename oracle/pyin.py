@@ -211,11 +211,26 @@ def viterbi_states(log_prob, log_trans, log_p_init, use_c=True):
     return state
 
 
-def decode(obs, p, use_c=True):
-    """sequence.viterbi(obs, transition, p_init=uniform) -> states uint16[F]."""
+def initial_distribution(p, p_init="unvoiced"):
+    """p_init handed to sequence.viterbi.  "unvoiced" (default) is librosa core/pitch.py::pyin as published
+    (0.8 ... 0.10): `p_init = np.zeros(2 * n_pitch_bins); p_init[n_pitch_bins:] = 1 / n_pitch_bins` -- the chain
+    starts in the unvoiced half, voiced states start at log(0 + tiny).  "uniform" is SURVEY.md P11's reading
+    (1/(2B) everywhere), kept as the documented alternative.  Neither can be checked against an installed librosa
+    here."""
+    B = p.n_pitch_bins
+    if p_init == "unvoiced":
+        v = np.zeros(2 * B)
+        v[B:] = 1 / B
+        return v
+    if p_init == "uniform":
+        return np.ones(2 * B) / (2 * B)
+    raise ValueError("p_init must be 'unvoiced' or 'uniform'")
+
+
+def decode(obs, p, use_c=True, p_init="unvoiced"):
+    """sequence.viterbi(obs, transition, p_init=p_init) -> states uint16[F]."""
     trans = transition_matrix(p)
-    S = 2 * p.n_pitch_bins
-    p_init = np.ones(S) / S
+    p_init = initial_distribution(p, p_init)
     log_trans = np.log(trans + TINY)
     log_prob = np.log(obs.T + TINY)
     log_p_init = np.log(p_init + TINY)
@@ -226,7 +241,7 @@ def decode(obs, p, use_c=True):
 # the public call
 # ----------------------------------------------------------------------------
 def pyin(y, sr=44100, hop_length=512, fmin=82.4068892282175, fmax=1046.5022612023945,
-         frame_length=2048, return_intermediates=False, use_c=True, block=2048):
+         frame_length=2048, return_intermediates=False, use_c=True, block=2048, p_init="unvoiced"):
     """librosa.pyin(y, fmin=, fmax=, sr=, hop_length=) with every other argument
     at its 0.10 default.  Returns (f0 float64[F] with NaN unvoiced,
     voiced_flag bool[F], voiced_prob float64[F])."""
@@ -239,7 +254,7 @@ def pyin(y, sr=44100, hop_length=512, fmin=82.4068892282175, fmax=1046.502261202
         yin[:, s : s + block] = cmnd(y_frames[:, s : s + block], p)
     shifts = parabolic_shifts(yin)
     obs, voiced_prob = observation(yin, shifts, p)
-    states = decode(obs, p, use_c=use_c)
+    states = decode(obs, p, use_c=use_c, p_init=p_init)
     f0 = p.freqs[states % p.n_pitch_bins]
     voiced_flag = states < p.n_pitch_bins
     f0 = f0.copy()

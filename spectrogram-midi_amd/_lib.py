@@ -12,6 +12,8 @@ STAGE_MEL, STAGE_RAKE, STAGE_PYIN, STAGE_RMS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0x
 (TREND_SMA, TREND_EMA, TREND_BOLLINGER, TREND_ARTICULATION, TREND_MACD, TREND_SLIDES, TREND_RSI, TREND_SAVGOL,
  TREND_KALMAN, TREND_HOLT, TREND_CONSENSUS) = range(1, 12)
 OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95
+PYIN_INIT_UNVOICED, PYIN_INIT_UNIFORM = 0, 1      # aegis_config.pyin_init
+_PYIN_INIT = {"unvoiced": 0, "uniform": 1, 0: 0, 1: 1}
 
 
 class AegisError(RuntimeError):
@@ -23,7 +25,7 @@ class AegisError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("sample_rate", C.c_int32), ("hop_length", C.c_int32), ("n_fft", C.c_int32),
                 ("n_mels", C.c_int32), ("fmin", C.c_double), ("fmax", C.c_double),
-                ("device", C.c_int32), ("reserved", C.c_int32), ("max_frames_per_pass", C.c_int64)]
+                ("device", C.c_int32), ("pyin_init", C.c_int32), ("max_frames_per_pass", C.c_int64)]
 
 
 class StreamFrames(C.Structure):
@@ -108,12 +110,16 @@ _DEBUG_DTYPES = {"persistent_fallbacks": np.int64, "obs_cycles": np.int64, "cqt_
 
 class Handle:
     """One analyze context (tables + workspace + stream) on one GPU.  device=-1 builds the
-    host tables only (no GPU touched)."""
+    host tables only (no GPU touched).  pyin_init: "unvoiced" (default; librosa core/pitch.py::pyin: p_init zero on
+    the voiced half, 1/B on the unvoiced half) or "uniform" (1/(2B) everywhere, SURVEY.md P11's reading)."""
 
     def __init__(self, sample_rate=44100, hop_length=512, n_fft=2048, n_mels=128, fmin=0.0, fmax=0.0,
-                 device=0, max_frames_per_pass=0, scipy_tables=True):
+                 device=0, max_frames_per_pass=0, scipy_tables=True, pyin_init="unvoiced"):
         self.lib = load()
-        cfg = Config(sample_rate, hop_length, n_fft, n_mels, fmin, fmax, device, 0, max_frames_per_pass)
+        if pyin_init not in _PYIN_INIT:
+            raise ValueError("pyin_init must be 'unvoiced' (librosa's p_init) or 'uniform'")
+        self.pyin_init = "uniform" if _PYIN_INIT[pyin_init] else "unvoiced"
+        cfg = Config(sample_rate, hop_length, n_fft, n_mels, fmin, fmax, device, _PYIN_INIT[pyin_init], max_frames_per_pass)
         h = C.c_void_p()
         rc = self.lib.aegis_create(C.byref(cfg), C.byref(h))
         if rc != OK:

@@ -167,7 +167,7 @@ PassParams base_params(const Tables &t) {
     p.sr = t.sr; p.hop = t.hop; p.n_mels = t.n_mels;
     p.min_period = t.min_period; p.max_period = t.max_period; p.n_lags = t.n_lags;
     p.n_bins = t.n_bins; p.half_width = t.half_width; p.width = t.width; p.n_cls = t.n_cls;
-    p.fmin = t.fmin; p.log_tiny = t.log_tiny; p.log_pinit = t.log_pinit;
+    p.fmin = t.fmin; p.log_tiny = t.log_tiny; p.log_pinit_v = t.log_pinit[0]; p.log_pinit_u = t.log_pinit[1];
     return p;
 }
 
@@ -247,6 +247,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (!h) { g_create_error = "out of host memory"; return AEGIS_ERR_NOMEM; }
     const std::string terr = h->tab.build(c.sample_rate, c.hop_length, c.n_fft, c.n_mels, c.fmin, c.fmax);
     if (!terr.empty()) { g_create_error = terr; delete h; return AEGIS_ERR_INVALID; }
+    if (!h->tab.set_pyin_init(c.pyin_init)) { g_create_error = "pyin_init must be AEGIS_PYIN_INIT_UNVOICED (0) or AEGIS_PYIN_INIT_UNIFORM (1)"; delete h; return AEGIS_ERR_INVALID; }
     h->device = c.device;
     h->max_frames_per_pass = c.max_frames_per_pass;
 
@@ -1425,6 +1426,7 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "yin_stride") return h->yin_stride;
     if (n == "obs_stride") return h->obs_stride;
     if (n == "last_frames") return h->last_frames;
+    if (n == "pyin_init") return t.pyin_init;
     return AEGIS_ERR_INVALID;
     } catch (...) { return abi_fail(const_cast<aegis_handle *>(h)); }
 }

@@ -47,7 +47,8 @@ struct PassParams {
     int32_t min_period, max_period, n_lags;
     int32_t n_bins, half_width, width, n_cls;
     double fmin;
-    double log_tiny, log_pinit;
+    double log_tiny;
+    double log_pinit_v, log_pinit_u;   // log(p_init + tiny) of a voiced / an unvoiced state
     uint32_t stages;
     // batch geometry (device arrays are per pass)
     const float *pcm;            // all clips of the batch

@@ -49,6 +49,20 @@ static double mel_to_hz(double m) {
     return m >= min_log_mel ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
 }
 
+// librosa core/pitch.py::pyin: `p_init = np.zeros(2 * n_pitch_bins); p_init[n_pitch_bins:] = 1 / n_pitch_bins`, then
+// sequence.viterbi takes log(p_init + tiny).  Mode 1 is the uniform start SURVEY.md P11 describes.
+bool Tables::set_pyin_init(int mode) {
+    if (mode != 0 && mode != 1) return false;
+    pyin_init = mode;
+    if (mode == 0) {
+        log_pinit[0] = std::log(0.0 + DBL_MIN);
+        log_pinit[1] = std::log(1.0 / n_bins + DBL_MIN);
+    } else {
+        log_pinit[0] = log_pinit[1] = std::log(1.0 / (2 * n_bins) + DBL_MIN);
+    }
+    return true;
+}
+
 std::string Tables::build(int sr_, int hop_, int n_fft_, int n_mels_, double fmin_, double fmax_) {
     sr = sr_; hop = hop_; n_fft = n_fft_; n_mels = n_mels_; fmin = fmin_; fmax = fmax_;
     if (n_fft != kFrameLength) return "only n_fft=2048 is built (the reference's value, aegis_engine.py:17)";
@@ -69,7 +83,7 @@ std::string Tables::build(int sr_, int hop_, int n_fft_, int n_mels_, double fmi
     n_cls = width;
     if (width < 3 || n_bins <= 2 * half_width + 1) return "transition width does not fit the pitch grid";
     log_tiny = std::log(0.0 + DBL_MIN);
-    log_pinit = std::log(1.0 / (2 * n_bins) + DBL_MIN);
+    set_pyin_init(0);
 
     // ---- Hann: scipy.signal.get_window('hann', n, fftbins=True) -------------------------------
     {

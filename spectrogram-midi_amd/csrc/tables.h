@@ -25,7 +25,8 @@ struct Tables {
     int width = 0;           // 2*half_width+1
     int n_cls = 0;           // source-row classes of the banded transition table (= width)
     double log_tiny = 0;     // log(0 + tiny)
-    double log_pinit = 0;    // log(1/(2B) + tiny)
+    double log_pinit[2] = {0, 0};   // log(p_init + tiny) of a voiced / an unvoiced state (set_pyin_init)
+    int pyin_init = 0;       // AEGIS_PYIN_INIT_*
     // tables
     std::vector<double> hann;          // [n_fft]
     std::vector<float> mel_dense;      // [n_mels][1+n_fft/2]
@@ -51,6 +52,8 @@ struct Tables {
     std::vector<double> twiddle;       // [n_fft][2]  cos, sin of -2*pi*m/n_fft
 
     std::string build(int sr, int hop, int n_fft, int n_mels, double fmin, double fmax);
+    // core/pitch.py::pyin's p_init: 0 = zeros(2B) with p_init[B:] = 1/B (librosa's code), 1 = uniform 1/(2B)
+    bool set_pyin_init(int mode);
 };
 
 // numpy's pairwise summation (umath loops: pairwise_sum_DOUBLE), used where the

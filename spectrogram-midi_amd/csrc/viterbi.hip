@@ -82,7 +82,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     if (act) {
         if (vt_begin == 0) {
             const double lp = v2 ? lunv[0] : lobs[b2];
-            myv = lp + p.log_pinit;
+            myv = lp + (v2 ? p.log_pinit_u : p.log_pinit_v);
         } else {
             myv = vst[j];
         }
@@ -202,7 +202,7 @@ __device__ __forceinline__ double row16_prefix_max(double v) {   // lane 15 of e
     v = dpp_fmax<0x118, 0xf>(v);   // row_shr:8
     return v;
 }
-// Wave reductions of float64 values that are all NEGATIVE or -inf (every Viterbi value is: log_pinit < 0, every
+// Wave reductions of float64 values that are all NEGATIVE or -inf (every Viterbi value is: log(p_init + tiny) < 0, every
 // log-transition < 0, observations <= log(1 + tiny)): for such values the larger double has the smaller bit pattern, so
 // the maximum is an unsigned minimum of the high words followed by one of the low words among the lanes that hold
 // that high word.  A 32-bit minimum takes its DPP operand directly (one v_min_u32_dpp per level: identity as the "old"
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     if (act) {
         const int tprev = vt_begin == 0 ? 0 : t_lo - 1;
         const double lp = vp ? lunv[tprev] : lobs[(int64_t)tprev * os + b2c];
-        myv = vt_begin == 0 ? lp + p.log_pinit : vst[j];
+        myv = vt_begin == 0 ? lp + (vp ? p.log_pinit_u : p.log_pinit_v) : vst[j];
         observed = !vp && lp != p.log_tiny;
         store_value(0, myv);
     }
@@ -475,7 +475,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         for (int tt = tp; tt > c0; --tt) s0 = ptr[(int64_t)tt * S + s0];
         org[j] = (uint16_t)s0;
     }
-    double G;                 // column max (all states)
+    double G = INFINITY;      // column max (all states); +inf until the first column is reduced, so that the first step of a
+                              // launch sees Gp = +inf (no bound on the dead voiced sources: full chain)
     double Gp = INFINITY;     // the column max one step earlier (unknown at the first step of a launch)
     int kg;
     // End-of-step bookkeeping, one barrier: block arg-max (lowest index on ties; wave max -> first lane holding it ->

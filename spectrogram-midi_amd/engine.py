@@ -30,7 +30,10 @@ def _require_finite(y):
 
 
 class AegisEngine:
-    def __init__(self, sample_rate=44100, hop_length=512, n_fft=2048, device=0, verbose=False):
+    def __init__(self, sample_rate=44100, hop_length=512, n_fft=2048, device=0, verbose=False, pyin_init="unvoiced"):
+        # pyin_init (not a reference argument): "unvoiced" = librosa.pyin's own initial distribution (the default, what
+        # the reference gets from librosa), "uniform" = the alternative reading documented in DESIGN.md section 1
+        self.pyin_init = pyin_init
         self.sr = sample_rate
         self.hop_length = hop_length
         self.n_fft = n_fft
@@ -44,7 +47,7 @@ class AegisEngine:
     def handle(self):
         if self._handle is None:
             self._handle = _lib.Handle(sample_rate=self.sr, hop_length=self.hop_length, n_fft=self.n_fft,
-                                       n_mels=128, fmin=_FMIN, fmax=_FMAX, device=self.device)
+                                       n_mels=128, fmin=_FMIN, fmax=_FMAX, device=self.device, pyin_init=self.pyin_init)
         return self._handle
 
     def close(self):

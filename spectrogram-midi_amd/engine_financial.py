@@ -13,7 +13,8 @@ from .smf import Track
 
 
 class AegisFinancialEngine:
-    def __init__(self, sample_rate=22050, hop_length=512, n_fft=2048, device=0, verbose=False):
+    def __init__(self, sample_rate=22050, hop_length=512, n_fft=2048, device=0, verbose=False, pyin_init="unvoiced"):
+        self.pyin_init = pyin_init      # see AegisEngine
         self.sr = sample_rate
         self.hop_length = hop_length
         self.n_fft = n_fft
@@ -26,7 +27,8 @@ class AegisFinancialEngine:
     def handle(self):
         if self._handle is None:
             self._handle = _lib.Handle(sample_rate=self.sr, hop_length=self.hop_length, n_fft=self.n_fft,
-                                       fmin=note_to_hz("E2"), fmax=note_to_hz("C6"), device=self.device)
+                                       fmin=note_to_hz("E2"), fmax=note_to_hz("C6"), device=self.device,
+                                       pyin_init=self.pyin_init)
         return self._handle
 
     def load_audio(self, file_path, start_time=0, end_time=None):

@@ -53,7 +53,7 @@ def gpu_handle():
 def test_clips():
     """Small ragged batch covering the edge cases: fixture track, sweep, silence, a clip
     shorter than one frame, noise, an empty clip."""
-    from spectrogram_midi_amd import signals as S
+    from tools import signals as S
     rng = np.random.default_rng(5)
     return {
         "guitar": S.guitar_test_track(),

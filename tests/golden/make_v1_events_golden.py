@@ -21,7 +21,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dsp, engine as oengine   # noqa: E402
-from spectrogram_midi_amd import signals   # noqa: E402
+from tools import signals   # noqa: E402
 
 REF = "/root/reference/aegis_engine_core/midi_logic.py"
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -35,7 +35,14 @@ KW = {"default": {}, "long_notes": {"min_note_duration_ms": 100, "sustain_ms": 2
 
 def clips():
     return {"guitar": signals.guitar_test_track(), "notes": signals.guitar_clip(6.0, seed=11),
-            "scale": signals.c_major_scale(44100), "poly": signals.polyphonic_clip(8.0, seed=5)}
+            "scale": signals.c_major_scale(44100), "poly": signals.polyphonic_clip(8.0, seed=5),
+            # pitched from sample 0: the one place pYIN's initial distribution shows.  Default = librosa's unvoiced
+            # start; the "_uniform" entry is the same audio under the alternative start (oracle p_init="uniform")
+            "pitched_start": signals.pitched_start_clip(), "pitched_start_uniform": signals.pitched_start_clip()}
+
+
+def p_init_of(name):
+    return "uniform" if name.endswith("_uniform") else "unvoiced"
 
 
 def fuzz_cases(n_cases=40, seed=20260220):
@@ -85,7 +92,7 @@ def main():
     ML = load_reference()
     arrays, meta = {}, {"semantics": "librosa-0.10-semantics/numpy1-dtypes", "sr": 44100, "hop": 512, "events": {}}
     for name, y in clips().items():
-        raw = oengine.audio_to_midi(y)
+        raw = oengine.audio_to_midi(y, p_init=p_init_of(name))
         for k in ("rake_mask", "f0", "voiced_flag", "voiced_probs", "rms"):
             arrays[f"{name}/{k}"] = raw[k]
         meta["events"][name] = {}

@@ -19,7 +19,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from oracle import dsp, engine as oengine, pyin as opyin, rake as orake   # noqa: E402
-from spectrogram_midi_amd import signals   # noqa: E402
+from tools import signals   # noqa: E402
 
 REF = "/root/reference/aegis_engine_core_v2"
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -1,6 +1,7 @@
 """CPU checks of the C-ABI library: it loads, exports every symbol include/aegis_hip.h declares,
 builds its host tables without touching a GPU (device=-1), those tables match the NumPy/SciPy
 constructions of the oracle, and analyze calls fail loudly without a device."""
+import ctypes
 import os
 import re
 
@@ -45,7 +46,7 @@ def test_header_symbols_are_exported():
     assert declared and declared == set(_lib.EXPORTS)
     for sym in declared:
         assert hasattr(lib, sym), sym
-    assert lib.aegis_abi_version() == 1
+    assert lib.aegis_abi_version() == 2
 
 
 def test_geometry(host_handle):
@@ -135,6 +136,21 @@ def test_no_cpu_fallback(host_handle):
     with pytest.raises(_lib.AegisError) as e:
         host_handle.analyze_batch([np.zeros(1000, np.float32)])
     assert e.value.code == _lib.ERR_DEVICE
+
+
+def test_pyin_init_is_a_create_time_choice():
+    """aegis_config.pyin_init: 0 (default) = librosa's unvoiced start, 1 = uniform; anything else is refused."""
+    for mode, code in (("unvoiced", 0), ("uniform", 1)):
+        h = _lib.Handle(device=-1, pyin_init=mode)
+        assert h.param("pyin_init") == code and h.pyin_init == mode
+        h.close()
+    h = _lib.Handle(device=-1)
+    assert h.param("pyin_init") == 0
+    h.close()
+    cfg = _lib.Config(44100, 512, 2048, 128, 0.0, 0.0, -1, 7, 0)
+    out = ctypes.c_void_p()
+    assert _lib.load().aegis_create(ctypes.byref(cfg), ctypes.byref(out)) == _lib.ERR_INVALID
+    assert b"pyin_init" in _lib.load().aegis_last_error(None)
 
 
 def test_product_does_not_import_oracle():
@@ -244,7 +260,7 @@ def test_representative_interior_rows_decode_like_the_true_matrix(host_handle):
     leaves the Viterbi: the oracle's dense decoder run with the TRUE matrix and with the matrix rebuilt from the kernels'
     table must give the same states on pYIN observations of tonal, polyphonic and noisy clips and on random sparse
     observation sequences (where near-ties are likeliest)."""
-    from spectrogram_midi_amd import signals
+    from tools import signals
     p = opyin.PyinParams()
     B, H, S = 441, 25, 882
     LT_true = np.log(opyin.transition_matrix(p) + opyin.TINY)

@@ -8,7 +8,8 @@ import numpy as np
 import torch.distributed as tdist
 import torch.multiprocessing as mp
 
-from spectrogram_midi_amd import dist, signals
+from spectrogram_midi_amd import dist
+from tools import signals
 
 
 def _free_port():

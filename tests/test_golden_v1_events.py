@@ -74,16 +74,22 @@ def test_fuzz_events_equal_the_reference(golden, impl):
 def test_gpu_raw_data_gives_the_reference_events(golden):
     """The same clips through the HIP path (C ABI) and the product's event logic: events equal what the reference's
     midi_logic.py produced from the oracle's frame arrays."""
-    from spectrogram_midi_amd import signals
+    from tools import signals
     from spectrogram_midi_amd.engine import AegisEngine
     arrays, meta = golden
     clips = {"guitar": signals.guitar_test_track(), "notes": signals.guitar_clip(6.0, seed=11),
-             "scale": signals.c_major_scale(44100), "poly": signals.polyphonic_clip(8.0, seed=5)}
-    eng = AegisEngine()
-    raws = eng.analyze_arrays(list(clips.values()))
-    for (clip, _), raw in zip(clips.items(), raws):
-        for k in ("rake_mask", "voiced_flag", "rms", "voiced_probs"):
-            np.testing.assert_array_equal(raw[k], arrays[f"{clip}/{k}"], err_msg=f"{clip} {k}")
-        for tag, want in meta["events"][clip].items():
-            assert_same(eng.extract_events(raw, None, **KW[tag]), want, ("gpu", clip, tag))
-    eng.close()
+             "scale": signals.c_major_scale(44100), "poly": signals.polyphonic_clip(8.0, seed=5),
+             "pitched_start": signals.pitched_start_clip()}
+    assert set(clips) | {"pitched_start_uniform"} == set(meta["events"])
+    # librosa's unvoiced start (the default) and the uniform start differ on a clip pitched from sample 0: frame 0
+    assert not arrays["pitched_start/voiced_flag"][0] and arrays["pitched_start_uniform/voiced_flag"][0]
+    for mode, names in (("unvoiced", list(clips)), ("uniform", ["pitched_start"])):
+        eng = AegisEngine(pyin_init=mode)
+        raws = eng.analyze_arrays([clips[n] for n in names])
+        for name, raw in zip(names, raws):
+            clip = name + ("_uniform" if mode == "uniform" else "")
+            for k in ("rake_mask", "voiced_flag", "rms", "voiced_probs", "f0"):
+                np.testing.assert_array_equal(raw[k], arrays[f"{clip}/{k}"], err_msg=f"{clip} {k}")
+            for tag, want in meta["events"][clip].items():
+                assert_same(eng.extract_events(raw, None, **KW[tag]), want, ("gpu", clip, tag))
+        eng.close()

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from oracle import cqt as ocqt
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import engine as oengine, pyin as opyin, dsp as odsp, rake as orake
-from spectrogram_midi_amd import _lib, audio_io, signals
+from spectrogram_midi_amd import _lib, audio_io
+from tools import signals
 from spectrogram_midi_amd.engine import AegisEngine
 from spectrogram_midi_amd.worker import _pyin_worker
 
@@ -87,6 +88,64 @@ def test_turbo_mode_matches_reference_chunking(eng):
     b = opyin.pyin(short)
     np.testing.assert_array_equal(a[1], b[1])
     eng.turbo_cores = None
+
+
+def _sine(freq, seconds, sr=44100, amp=0.5):
+    t = np.arange(int(sr * seconds)) / sr
+    return (amp * np.sin(2 * np.pi * freq * t)).astype(np.float32)
+
+
+@pytest.mark.parametrize("sr,hop", [(44100, 512), (22050, 512), (44100, 256)])
+def test_pyin_initial_distribution_modes(sr, hop, test_clips):
+    """aegis_config.pyin_init: librosa's unvoiced start (default) and the uniform start, both against the oracle in the
+    same mode, on clips that are pitched from sample 0 -- the only frames the choice reaches.  44.1 kHz / 512 and
+    22.05 kHz / 512 run the band kernels (H = 25, 50), hop 256 the generic kernel."""
+    clips = {"sine880": _sine(880.0, 0.5, sr), "sine1000": _sine(1000.0, 0.5, sr), "sine110": _sine(110.0, 2.0, sr),
+             "tiny": test_clips["tiny"], "pitched_start": signals.pitched_start_clip(sr),
+             "guitar": signals.guitar_test_track(sr=sr), "silence": np.zeros(3000, np.float32)}
+    got = {}
+    for mode in ("unvoiced", "uniform"):
+        h = _lib.Handle(sample_rate=sr, hop_length=hop, pyin_init=mode)
+        assert h.param("pyin_init") == (1 if mode == "uniform" else 0)
+        res = h.analyze_batch(list(clips.values()), stages=_lib.STAGE_PYIN)
+        for (name, y), r in zip(clips.items(), res):
+            f0, vf, vp = opyin.pyin(y, sr=sr, hop_length=hop, p_init=mode)
+            np.testing.assert_array_equal(r["voiced_flag"], vf, err_msg=f"{mode} {name}")
+            np.testing.assert_array_equal(np.nan_to_num(r["f0"]), np.nan_to_num(f0), err_msg=f"{mode} {name}")
+            np.testing.assert_array_equal(r["voiced_prob"], vp, err_msg=f"{mode} {name}")
+            got[mode, name] = r["voiced_flag"]
+        # the streamed form of the same clip ends in the same arrays (the first column is built by the first push)
+        st = h.open_stream(max_seconds=4.0)
+        y = clips["pitched_start"]
+        for a in range(0, len(y), 2048):
+            st.push(y[a:a + 2048])
+        out = st.close()
+        st.free()
+        np.testing.assert_array_equal(out["voiced_flag"], got[mode, "pitched_start"])
+        h.close()
+    # librosa's start never voices frame 0; the uniform start does where frame 0 carries a trough on the track
+    for name in clips:
+        assert not got["unvoiced", name][0], name
+        np.testing.assert_array_equal(got["unvoiced", name][1:], got["uniform", name][1:], err_msg=name)
+    if (sr, hop) == (44100, 512):
+        assert got["uniform", "sine880"][0] and got["uniform", "sine1000"][0] and got["uniform", "pitched_start"][0]
+
+
+def test_turbo_chunks_start_unvoiced_like_librosa():
+    """Every Turbo chunk (aegis_engine.py:197-210) is its own pyin call: its first frame is where p_init acts."""
+    y = _sine(880.0, 6.0)
+    for mode in ("unvoiced", "uniform"):
+        e = AegisEngine(pyin_init=mode)
+        e.turbo_cores = 4
+        f0, vf, vp = e._parallel_pitch_tracking(y)
+        rf0, rvf, rvp = oengine.parallel_pitch_tracking(y, num_cores=4, p_init=mode)
+        np.testing.assert_array_equal(vf, rvf)
+        np.testing.assert_array_equal(np.nan_to_num(f0), np.nan_to_num(rf0))
+        first = np.cumsum([0] + [1 + (b - a) // 512 for a, b in e._turbo_spans(len(y))])[:-1]
+        assert vf[first].any() == (mode == "uniform")
+        e.close()
+    with pytest.raises(ValueError):
+        _lib.Handle(pyin_init="voiced")
 
 
 def test_pyin_worker(eng):

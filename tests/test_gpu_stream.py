@@ -5,7 +5,8 @@ against the oracle elsewhere)."""
 import numpy as np
 import pytest
 
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 
 pytestmark = pytest.mark.gpu
 

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import smf as osmf
-from spectrogram_midi_amd import audio_io, signals
+from spectrogram_midi_amd import audio_io
+from tools import signals
 from spectrogram_midi_amd.engine_financial import AegisFinancialEngine
 from spectrogram_midi_amd.guitar import apply_guitar_filters
 from spectrogram_midi_amd.midi_logic_financial import get_midi_events_financial

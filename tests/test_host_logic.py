@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from oracle import engine as oengine, smf as osmf
-from spectrogram_midi_amd import audio_io, dist, midi_logic, signals, smf
+from spectrogram_midi_amd import audio_io, dist, midi_logic, smf
+from tools import signals
 from spectrogram_midi_amd.engine import AegisEngine
 
 

@@ -39,13 +39,62 @@ def test_frame_count_and_padding():
 
 
 def test_pure_sine_tracks_a2():
-    f0, voiced, prob = opyin.pyin(sine(110.0, 2.0))
-    inner = slice(4, -4)
+    """Every frame is pinned, the first ones included: frame 0 (half zero padding, voiced_prob 0.01) starts the chain
+    unvoiced at the A2 bin's twin, frame 1 (three quarters of a window) lands one bin high, everything else sits on
+    bin 50 = 110 Hz until the zero-padded last frame (one bin high again)."""
     p = opyin.PyinParams()
-    assert voiced[inner].all()
-    assert np.all(f0[inner] == p.freqs[50])          # fmin * 2^(50/120) = 110 Hz bin
-    assert abs(p.freqs[50] - 110.0) < 1e-9
-    assert np.all(prob[inner] > 0.99)
+    for mode in ("unvoiced", "uniform"):
+        f0, voiced, prob, it = opyin.pyin(sine(110.0, 2.0), p_init=mode, return_intermediates=True)
+        states = it["states"].astype(int)
+        assert len(states) == 173
+        assert states[0] == 441 + 51 and not voiced[0] and np.isnan(f0[0])
+        assert states[1] == 51 and states[-1] == 51 and np.all(states[2:-1] == 50)
+        assert voiced[1:].all() and np.all(f0[2:-1] == p.freqs[50])      # fmin * 2^(50/120) = 110 Hz bin
+        assert abs(p.freqs[50] - 110.0) < 1e-9
+        assert prob[0] == 0.01 and np.all(prob[2:-1] > 0.99)
+
+
+def test_initial_distribution_is_librosas_unvoiced_start():
+    """core/pitch.py::pyin: p_init = zeros(2B); p_init[B:] = 1/B.  With it no clip and no Turbo chunk can start voiced
+    (a voiced first state costs log(tiny)); the uniform alternative voices frame 0 of a clip that is pitched from
+    its first sample."""
+    p = opyin.PyinParams()
+    a = opyin.initial_distribution(p)
+    assert a.shape == (882,) and np.all(a[:441] == 0) and np.all(a[441:] == 1 / 441) and abs(a.sum() - 1) < 1e-12
+    assert np.all(opyin.initial_distribution(p, "uniform") == 1 / 882)
+    with pytest.raises(ValueError):
+        opyin.initial_distribution(p, "voiced")
+    for f in (880.0, 1000.0):
+        y = sine(f, 0.5)
+        lib = opyin.pyin(y)                           # default = librosa's
+        uni = opyin.pyin(y, p_init="uniform")
+        assert not lib[1][0] and uni[1][0]            # frame 0: unvoiced vs voiced
+        assert np.array_equal(lib[1][1:], uni[1][1:]) and np.array_equal(lib[2], uni[2])
+        assert np.array_equal(np.nan_to_num(lib[0][1:]), np.nan_to_num(uni[0][1:]))
+    # direct: observations that favour a voiced bin at t = 0 (0.6 against (1 - 0.6)/441 per unvoiced state)
+    obs = np.zeros((882, 3))
+    obs[100, :] = 0.6
+    obs[441:, :] = 0.4 / 441
+    assert list(opyin.decode(obs, p, p_init="uniform")) == [100, 100, 100]
+    assert list(opyin.decode(obs, p)) == [441 + 100, 100, 100]
+    assert list(opyin.decode(obs, p, use_c=False)) == [441 + 100, 100, 100]
+
+
+def test_turbo_chunks_start_unvoiced():
+    """aegis_engine.py:197-210: every Turbo chunk is its own pyin call, so every chunk of a sustained note starts
+    with an unvoiced frame under librosa's start."""
+    y = sine(880.0, 6.0)
+    f0, voiced, prob = oengine.parallel_pitch_tracking(y, num_cores=4)
+    spans = oengine.turbo_chunks(len(y), SR, 512, 4)
+    first, k = [], 0
+    for lo, hi in spans:
+        first.append(k)
+        k += 1 + (hi - lo) // 512
+    assert k == len(voiced) and not voiced[first].any()
+    uni = oengine.parallel_pitch_tracking(y, num_cores=4, p_init="uniform")
+    assert uni[1][first].any()                         # the uniform start voices the chunk that begins on a zero crossing
+    rest = np.setdiff1d(np.arange(k), first)
+    assert np.array_equal(voiced[rest], uni[1][rest])
 
 
 def test_silence_is_unvoiced():

@@ -2,7 +2,7 @@
 block-wise Karplus-Strong of signals.py must satisfy the generator's sample recurrence."""
 import numpy as np
 
-from spectrogram_midi_amd import signals
+from tools import signals
 
 
 def test_karplus_strong_satisfies_the_sample_recurrence():

@@ -4,7 +4,8 @@ fraction of the f32-MFMA peak (157.3 TF, MI355X_MICROARCH.md)."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 
 n_clips = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 secs = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0

@@ -3,7 +3,8 @@ Prints one JSON line with p50 / p99 wall time per push (host call to host return
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 
 n_push = int(sys.argv[1]) if len(sys.argv) > 1 else 4000
 y = signals.guitar_clip(n_push * 2048 / 44100 + 1.0, seed=1)

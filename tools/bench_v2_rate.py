@@ -4,7 +4,8 @@ import sys, os, time
 import numpy as np, torch
 torch.zeros(1, device="cuda")          # torch first: it must see the GPU before the library has opened it
 sys.path.insert(0, os.getcwd())
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 sr = 22050
 clips = [signals.guitar_clip(180.0, seed=1 + i % 8, sr=sr) if "sr" in signals.guitar_clip.__code__.co_varnames else None for i in range(64)]
 if clips[0] is None:

@@ -7,7 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for k in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
     os.environ[k] = "1"
 from oracle import engine as oe
-from spectrogram_midi_amd import signals
+from tools import signals
 
 
 def whole_clip(seed):

@@ -1,6 +1,7 @@
 import sys, os
 sys.path.insert(0, os.getcwd())
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 clips = [signals.polyphonic_clip(30.0, seed=100 + i % 4) for i in range(64)]
 h = _lib.Handle(); h.cqt(clips[:2]); h.cqt(clips)
 v = h.debug_fetch("cqt_cycles")

@@ -4,7 +4,8 @@ AEGIS_BALANCED_CHUNK=0 AEGIS_TIME_CHUNK=65536 AEGIS_HIP_LIB=_ablate/lib_ab256.so
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 y = signals.guitar_clip(180.0, seed=1)
 clips = [np.roll(y, 1000 * i) for i in range(64)]
 h = _lib.Handle()

@@ -102,3 +102,12 @@ def c_major_scale(sr=22050, seed=7):
     y[s:s + d] += rng.normal(0, 0.8, d)
     y += rng.normal(0, 0.02, len(y))
     return y.astype(np.float32)
+
+
+def pitched_start_clip(sr=44100):
+    """A clip that is pitched from its very first sample (880 Hz sine at phase 0, a pause, a 220 Hz sine): frame 0 is
+    where the initial distribution of pYIN's HMM decides -- librosa's unvoiced start leaves it unvoiced, the uniform
+    start voices it (tests of both modes)."""
+    t = np.arange(int(0.8 * sr)) / sr
+    return np.concatenate([0.5 * np.sin(2 * np.pi * 880.0 * t), np.zeros(int(0.3 * sr)),
+                           0.4 * np.sin(2 * np.pi * 220.0 * t)]).astype(np.float32)

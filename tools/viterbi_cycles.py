@@ -2,7 +2,8 @@
 AEGIS_HIP_LIB=_ablate/lib_ab64.so python tools/viterbi_cycles.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from spectrogram_midi_amd import _lib, signals
+from spectrogram_midi_amd import _lib
+from tools import signals
 clips = [signals.guitar_clip(60.0, seed=1 + i) for i in range(4)]
 h = _lib.Handle()
 h.analyze_batch(clips[:1])
