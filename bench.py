@@ -470,7 +470,9 @@ def main():
                        "backend": None if world == 1 else ("gloo" if args.rehearse_on_one_gpu else "nccl (RCCL)")},
         }
         if vstats is not None and vstats["wave_steps"] > 0:
-            line["viterbi_list_only_rate"] = round(vstats["list_only"] / vstats["wave_steps"], 5)
+            line["viterbi_list_only_rate"] = round(vstats["list_only"] / max(1, vstats["wave_steps"] - vstats["skipped"]), 5)
+            # voiced waves whose 64 targets are all dead at an easy frame skip the step (exact: viterbi.hip)
+            line["viterbi_skipped_wave_steps"] = round(vstats["skipped"] / vstats["wave_steps"], 5)
         # calls the library repeated with one Viterbi launch per time chunk because its single launch per pass found no
         # frame stage running beside it (0 unless something serialises kernels, e.g. a counter-collecting profiler)
         line["persistent_fallbacks"] = int(handle.debug_fetch("persistent_fallbacks")[0])

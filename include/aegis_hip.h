@@ -204,8 +204,9 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name);
  * frame stage leaves in HBM), "yin" f64[F*yin_stride] (the CMND rows: only on handles created under AEGIS_DEBUG_STAGES=1),
  * "logobs" f64[F*obs_stride], "logunv" f64[F], "states" i32[F], "melpow" f32[F*n_mels]}.
  * Returns the element count available; copies min(count, cap).
- * "viterbi_stats" i64[2] (reading resets; "viterbi_stats_peek" does not): wave-steps of the band Viterbi since the last
- * reset and how many of them took the exact observed-sources-only path (bench.py reports the ratio).
+ * "viterbi_stats" i64[3] (reading resets; "viterbi_stats_peek" does not): wave-steps of the band Viterbi since the last
+ * reset, how many of them took the exact observed-sources-only path, and how many were voiced waves that skipped the step
+ * because all their targets were dead at an easy frame (bench.py reports the ratios).
  * "persistent_fallbacks" i64[1]: calls this handle repeated with one Viterbi launch per time chunk after its single
  * launch per pass gave up waiting for the frame stage (kernels serialised by a counter-collecting profiler, for one).
  * "throw_bad_alloc" / "throw_length_error" / "throw_runtime_error" / "throw_int": test hooks of the exception barrier

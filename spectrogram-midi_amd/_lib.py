@@ -105,7 +105,7 @@ def load():
 
 
 _TABLE_DTYPES = {"mel_dense": np.float32}
-_DEBUG_DTYPES = {"persistent_fallbacks": np.int64, "obs_cycles": np.int64, "cqt_cycles": np.int64, "viterbi_cycles": np.int64, "frame_cycles": np.int64, "states": np.int32, "melpow": np.float32}
+_DEBUG_DTYPES = {"persistent_fallbacks": np.int64, "obs_cycles": np.int64, "cqt_cycles": np.int64, "viterbi_cycles": np.int64, "viterbi_spans": np.int64, "frame_cycles": np.int64, "states": np.int32, "melpow": np.float32}
 
 
 class Handle:
@@ -198,15 +198,16 @@ class Handle:
         return int(self.lib.aegis_last_kernel_launches(self._h, name.encode()))
 
     def viterbi_stats(self, reset=True):
-        """{"wave_steps", "list_only"}: voiced-source evaluations of the band Viterbi since the last reset and how many
-        of them took the exact observed-sources-only path (viterbi.hip); None on a host-only handle."""
+        """{"wave_steps", "list_only", "skipped"}: wave-steps of the band Viterbi since the last reset, how many of them
+        took the exact observed-sources-only path, and how many were voiced waves with nothing but dead targets at an
+        easy frame, which skip the step (viterbi.hip); None on a host-only handle."""
         if self.device < 0:
             return None
-        v = np.zeros(2, np.int64)
-        n = int(self.lib.aegis_debug_fetch(self._h, b"viterbi_stats" if reset else b"viterbi_stats_peek", v.ctypes.data, 2))
+        v = np.zeros(3, np.int64)
+        n = int(self.lib.aegis_debug_fetch(self._h, b"viterbi_stats" if reset else b"viterbi_stats_peek", v.ctypes.data, 3))
         if n < 0:
             return None
-        return {"wave_steps": int(v[0]), "list_only": int(v[1])}
+        return {"wave_steps": int(v[0]), "list_only": int(v[1]), "skipped": int(v[2])}
 
     def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True):
         """clips: list of float32 1-D arrays (host).  Returns a list of per-clip dicts with the

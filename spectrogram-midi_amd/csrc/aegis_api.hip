@@ -288,8 +288,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     CRTHIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, c.device));
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
-    CRT(ensure(h, h->vstats, 16));
-    CRTHIP(hipMemset(h->vstats.p, 0, 16));
+    CRT(ensure(h, h->vstats, 32));
+    CRTHIP(hipMemset(h->vstats.p, 0, 32));
     CRTHIP(cqt_configure());
 
     const Tables &t = h->tab;
@@ -1482,18 +1482,18 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
         if (dst && cap > 0) *static_cast<int64_t *>(dst) = h->persistent_fallbacks;
         return 1;
     }
-    else if (n == "viterbi_stats" || n == "viterbi_stats_peek") {      // [wave-steps, observed-sources-only wave-steps]
+    else if (n == "viterbi_stats" || n == "viterbi_stats_peek") {      // [wave-steps, observed-sources-only wave-steps, skipped voiced wave-steps]
         if (h->device < 0 || !h->vstats.p) return AEGIS_ERR_INVALID;
         if (dst && cap > 0) {
-            long long v[2];
+            long long v[3];
             std::lock_guard<std::mutex> lock(h->mu);
             HIPCHK(h, hipSetDevice(h->device));
             HIPCHK(h, hipDeviceSynchronize());
-            HIPCHK(h, hipMemcpy(v, h->vstats.p, 16, hipMemcpyDeviceToHost));
-            if (n == "viterbi_stats") HIPCHK(h, hipMemset(h->vstats.p, 0, 16));
-            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 2) * 8);
+            HIPCHK(h, hipMemcpy(v, h->vstats.p, 24, hipMemcpyDeviceToHost));
+            if (n == "viterbi_stats") HIPCHK(h, hipMemset(h->vstats.p, 0, 24));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 3) * 8);
         }
-        return 2;
+        return 3;
     }
     else if (n == "obs_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;
@@ -1527,6 +1527,17 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
             std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 128) * 8);
         }
         return 128;
+    }
+    else if (n == "viterbi_spans") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {                     // reading resets the counters
+            long long v[272];
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, viterbi_span_fetch(v));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 272) * 8);
+        }
+        return 272;
     }
     else if (n == "cqt_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;

@@ -116,6 +116,7 @@ void launch_stream_gather(const StreamCtl *ctl, const float *rms, const double *
 hipError_t obs_debug_fetch(long long *dst);                  // pyin_obs_kernel section cycles (AEGIS_ABLATE&256)
 hipError_t frame_debug_fetch(long long *dst);                // frame_yin_kernel section cycles (AEGIS_ABLATE&128)
 hipError_t viterbi_debug_fetch(long long *dst, bool reset);   // per-wave section cycles (zeros unless AEGIS_ABLATE&64)
+hipError_t viterbi_span_fetch(long long *dst);               // arg-max span statistics (zeros unless AEGIS_ABLATE&512); reading resets
 hipError_t viterbi_configure();   // raises the dynamic-LDS limits once (all kernels)
 hipError_t viterbi_set_lds_limits();   // viterbi.hip's share of it
 

@@ -301,6 +301,13 @@ __device__ long long g_vit_dbg[16 * 8];
 #define VIT_TICK(k)
 #endif
 
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 512)
+// Span statistics of the unvoiced-source arg-max (tools/viterbi_spans.py): [0..127] histogram of r(last lane) - r(first
+// lane) per wave-step, [128..191] of the same over aligned groups of 8 lanes, [192] pairs of neighbouring lanes whose
+// arg-max source DEcreases with the target bin (none, if the concavity argument holds), [193] wave-steps counted,
+// [194] 8-lane groups counted, [200..263] histogram of the arg-max offset |r(b') - b'|.
+__device__ unsigned long long g_vit_span[272];
+#endif
 #ifndef AEGIS_VIT_GATE
 #define AEGIS_VIT_GATE 1       // edge rows: reach gates + immediate table offsets (0: compare / select per candidate)
 #endif
@@ -382,6 +389,14 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     if (AEGIS_VIT_GATE && LT_LDS && H == 25) for (int i = tid; i < NGATE; i += nthr) gate[i] = i < KG ? -INFINITY : INFINITY;
     const double *lti0 = blt.v[0 * 2 + vp];   // interior row, source v = 0, target v' = vp
     const double *lti1 = blt.v[1 * 2 + vp];   // source v = 1
+    // The interior row of the unvoiced-source block, RESIDENT in scalar registers for the whole kernel.  The row is
+    // symmetric bit for bit (lt[d] == lt[2H - d]: the same triangle entry over the same row sum; launch_viterbi checks),
+    // so H + 1 values = 2H + 2 SGPRs hold it.  Read from the kernarg segment inside the step loop, as the compiler does
+    // for the full 4 x (2H + 1) table, every few candidates wait on an s_load -- and s_waitcnt lgkmcnt(0) is the only
+    // way to wait for a scalar load, so each of those waits also drains the LDS reads in flight: the chain ran at the
+    // scalar cache's latency (~25 waits of ~100 cycles per step), not at the vector issue rate.  The values are taken from
+    // the LDS copy of the table through v_readfirstlane (below, once the copy is complete): nothing the compiler could
+    // re-materialise from the kernarg segment inside the loop.
     constexpr int kSentinel = 0;
 
     const int c = p.order[blockIdx.x];
@@ -397,6 +412,16 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     int32_t *__restrict__ states = p.states + f0;
     const int nch = (T - 1 + C - 1) / C;
     __syncthreads();
+    double ku[H + 1];         // see above: ku[i] = lt(1 -> vp)[i] = lt(1 -> vp)[2H - i], in SGPRs
+    {
+        const double *row = lt_e1 + (PK ? pk_int_start<H>() : H * W);
+#pragma unroll
+        for (int i = 0; i <= H; ++i) {
+            const double t = LT_LDS ? row[i] : lti1[i];
+            ku[i] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)), __builtin_amdgcn_readfirstlane(__double2loint(t)));
+        }
+    }
+    auto ku_at = [&](int d) { return ku[d <= H ? d : W - 1 - d]; };     // lt of offset d (compile-time index)
 
     // Persistent launch: the steps are run chunk by chunk, each run after the chunk's observations are in memory.  Lane 0
     // of the workgroup polls the chunk's flag (agent-scope acquire: the producer ran on other CUs, possibly behind another
@@ -554,6 +579,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int lp_stride = vp ? 1 : os;
     int ph = 0;               // step parity: columns, origin maps and list slots all alternate with it
     int n_list = 0;           // wave-steps that took the observed-sources-only path (wave-uniform)
+    int n_skip = 0;           // voiced wave-steps skipped: every target dead at an easy frame
     // The steps of this launch, cut at the time-chunk boundaries when the launch spans several chunks (persistent
     // launch): the wait sits between two runs of the step loop, not inside it.
     int t = t_lo;
@@ -566,11 +592,34 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             return;
         }
     }
+    // Observations are requested ONE STEP AHEAD (never past the run: the next time chunk's rows may not be written yet):
+    // a step starts by deciding, from its own observations, whether this wave has anything to compute.
+    double lp_n = lp_base[(int64_t)t * lp_stride];
+    double lu_n = lunv[t];
     for (; t < t_end; ++t) {
         VIT_TICK(5)
         // every lane loads (lanes without a state read bin 0): the sum below then needs no wait at a control-flow join
-        const double lp = lp_base[(int64_t)t * lp_stride];
+        const double lp = lp_n, lu = lu_n;
+        {
+            const int tn = min(t + 1, t_end - 1);
+            lp_n = lp_base[(int64_t)tn * lp_stride];
+            lu_n = lunv[tn];
+        }
         const int cur = __builtin_amdgcn_readfirstlane(ph);
+        // Dead voiced targets.  Call a voiced state dead at frame t when its observation is log(tiny), and frame t easy
+        // when its unvoiced observation is not (voiced_prob < 1: the unvoiced observation is then > -43).  A dead state
+        // (0, b) of an easy frame collects the same sources as its unvoiced twin (1, b) through rows that differ only by
+        // the voicing factor (|log .99 - log .01| = 4.6), so value(1, b) >= value(0, b) + (logunv - log tiny) - 4.6
+        // > value(0, b) + 660; as a source for the next column the twin loses at most another 4.6.  Such a state
+        // therefore never wins or ties a maximisation, is never the column maximum and never lies on the decoded path:
+        // its value may be replaced by -inf and its back-pointer left unwritten without changing any result.  A voiced
+        // wave ALL of whose targets are dead at an easy frame (59 % of the voiced wave-steps on the bench clips) does
+        // exactly that and goes straight to the end-of-step barrier.
+        // (an easy frame's unvoiced observation is log((1 - voiced_prob) / B + tiny) >= log(2^-53 / B) = -42.8, a hard
+        // frame's is log(tiny) = -708.4: the high word of -100.0 separates them)
+        // (negative doubles: the larger magnitude has the larger high word, as signed integers too)
+        const bool skip = !vp && __builtin_amdgcn_readfirstlane(__double2hiint(lu)) < __double2hiint(-100.0) &&
+                          __ballot(act && lp != p.log_tiny) == 0ull;
         const double *colr = val + cur * PB;        // the column being read
         // observed bins within reach of this wave's targets, [wlo - H, whi + H], span <= 3 mask words: the masks and
         // this lane's share of those words' values (bin 64 w + lane, voiced) are fetched here, far ahead of the list
@@ -623,7 +672,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 32)
         if (vp) {   // timing experiment: voiced waves skip all candidate work (values are wrong)
 #else
-        {
+        if (!skip) {
 #endif
         // ---- unvoiced sources (v = 1): always the full band ---------------------------------------------------
         constexpr int HALF = (W + 1) / 2;
@@ -644,9 +693,9 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
                 const int d0 = g * GS < W - GS ? g * GS : W - GS;
-                double m = vi1[d0] + lti1[W - 1 - d0];
+                double m = vi1[d0] + ku_at(W - 1 - d0);
 #pragma unroll
-                for (int k = 1; k < GS; ++k) m = fmax(m, vi1[d0 + k] + lti1[W - 1 - d0 - k]);
+                for (int k = 1; k < GS; ++k) m = fmax(m, vi1[d0 + k] + ku_at(W - 1 - d0 - k));
                 gm[g] = m;
             }
             best1 = gm[0];
@@ -686,6 +735,21 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
             if (best1b > best1) { best1 = best1b; code1 = code1b; }
         }
         int src1 = b2c + code1 - H;
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 512)
+        if (blockIdx.x < 8) {      // interior-row sources only, as the chain above saw them
+            const int r = src1;
+            const int rn = __shfl_down(r, 1);
+            const bool an = __shfl_down(act ? 1 : 0, 1) != 0;
+            if (act && an && lane < 63 && rn < r) atomicAdd(&g_vit_span[192], 1ull);
+            const int r0 = __shfl(r, lane & ~7), r7 = __shfl(r, lane | 7);
+            const bool a7 = __shfl(act ? 1 : 0, lane | 7) != 0;
+            if (a7 && (lane & 7) == 0) { atomicAdd(&g_vit_span[128 + min(63, max(0, r7 - r0))], 1ull); atomicAdd(&g_vit_span[194], 1ull); }
+            const int nact = __popcll(__ballot(act));
+            const int rl = __shfl(r, nact - 1), rf = __shfl(r, 0);
+            if (lane == 0 && nact > 0) { atomicAdd(&g_vit_span[min(127, max(0, rl - rf))], 1ull); atomicAdd(&g_vit_span[193], 1ull); }
+            if (act) atomicAdd(&g_vit_span[200 + min(63, abs(code1 - H))], 1ull);
+        }
+#endif
 #if !(defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 1))
         if (wave_low) {     // low-edge sources precede the interior ones in state order: they win ties
             double eb1 = -INFINITY;
@@ -819,9 +883,12 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         }
         }
         const double sum = lp + best;
-        myv = act ? sum : -INFINITY;
+        myv = (act && !skip) ? sum : -INFINITY;
         observed = act && !vp && lp != p.log_tiny;
-        if (act) {
+        n_skip += skip ? 1 : 0;
+        if (skip) {
+            if (act) store_value(cur ^ 1, -INFINITY);
+        } else if (act) {
             store_value(cur ^ 1, myv);
             ptr[(int64_t)t * S + j] = (uint16_t)bi;
             const uint16_t o = ((t - 1) % C == 0) ? (uint16_t)bi : org[cur * S + bi];
@@ -846,6 +913,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     if (p.vstats != nullptr && lane == 0 && t_hi > t_lo) {
         atomicAdd(&p.vstats[0], (unsigned long long)(t_hi - t_lo));
         atomicAdd(&p.vstats[1], (unsigned long long)n_list);
+        atomicAdd(&p.vstats[2], (unsigned long long)n_skip);
     }
     if (t_hi < T) {                       // more launches follow: hand the column over
         if (act) vst[j] = myv;
@@ -865,6 +933,16 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
     }
 }
+
+#if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 512)
+hipError_t viterbi_span_fetch(long long *dst) {
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_vit_span), sizeof(long long) * 272);
+    if (e == hipSuccess) { static long long z[272]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_vit_span), z, sizeof(z)); }
+    return e;
+}
+#else
+hipError_t viterbi_span_fetch(long long *dst) { for (int i = 0; i < 272; ++i) dst[i] = 0; return hipSuccess; }
+#endif
 
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 64)
 hipError_t viterbi_debug_fetch(long long *dst, bool reset) {

@@ -148,6 +148,23 @@ def test_turbo_chunks_start_unvoiced_like_librosa():
         _lib.Handle(pyin_init="voiced")
 
 
+def test_dead_voiced_waves_skip_their_steps(eng):
+    """viterbi.hip: a voiced wave with nothing but dead targets at an easy frame skips the step.  The rule is exact (every
+    parity test in this directory runs with it); here: it fires, on tonal and on noisy material, and the counters add up."""
+    h = eng.handle
+    for y in (signals.guitar_clip(8.0, seed=2), signals.guitar_clip(6.0, seed=3, noise_dbfs=-12.0), np.zeros(44100, np.float32)):
+        h.viterbi_stats(reset=True)
+        r = h.analyze_batch([y], stages=_lib.STAGE_PYIN)[0]
+        st = h.viterbi_stats(reset=True)
+        F = len(r["f0"])
+        assert st["wave_steps"] == 14 * (F - 1)
+        assert 0 < st["skipped"] <= 7 * (F - 1) and st["list_only"] <= st["wave_steps"] - st["skipped"]
+        f0, vf, vp = opyin.pyin(y)
+        np.testing.assert_array_equal(r["voiced_flag"], vf)
+        np.testing.assert_array_equal(np.nan_to_num(r["f0"]), np.nan_to_num(f0))
+    assert st["skipped"] == 7 * (F - 1)          # silence: no voiced target is ever observed
+
+
 def test_pyin_worker(eng):
     chunk = signals.guitar_clip(3.0, seed=4)
     f0, vf, vp = _pyin_worker((chunk, 44100, 512))
