@@ -8,12 +8,15 @@ PCM already resident in HBM, outputs left in HBM.  One process per GPU; rank 0 p
     python bench.py --gpus N --steps K --warmup W          # starts the N rank processes itself
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or is started as a rank
 
---config headline (default): the per-GPU shard of BASELINE.json configs[3] (512-clip folder over 8 GPUs = 64 clips
-    per GPU) with clips of the configs[1] shape (3-minute 44.1 kHz mono guitar clips).  Weak scaling: every rank gets
-    its own 64 clips; with N > 1 the ranks' note events are gathered over RCCL after the timed steps (reported apart).
---config folder: configs[3] as written -- 512 seeded clips with durations U(30, 330) s (the collector's filter,
-    folder_audio_collector.py:113), one in eight polyphonic and one in eight noisy, assigned longest-first to the ranks
-    (dist.shard_clips), one ragged batch per rank, events extracted and gathered (dist.gather_events).  Strong scaling.
+--config folder (default): BASELINE.json configs[3] as written -- 512 seeded clips with durations U(30, 330) s (the
+    collector's filter, folder_audio_collector.py:113), one in eight polyphonic and one in eight noisy, assigned
+    longest-first to the ranks (dist.shard_clips), one ragged batch per rank, events extracted and gathered
+    (dist.gather_events).  STRONG scaling: the folder is the same at every N, so the ragged tail of a rank's longest clip
+    shows in the N = 8 line.  Sub-records of the same run: `uniform_shard` (64 x 180 s on one GPU, the workload earlier
+    rounds quoted), `host_inclusive` (host NumPy buffers in and out through aegis_analyze_batch: PCIe included) and
+    `engine_e2e` (AegisEngine.analyze_arrays + extract_events to Standard MIDI File bytes).
+--config shard (alias headline): the per-GPU shard of configs[3] with clips of the configs[1] shape (64 x 3-minute
+    clips per GPU).  Weak scaling.
 --config cqt: configs[2] -- 64 x 30 s polyphonic clips through the 84-bin constant-Q filter bank (MFMA path).
 """
 import argparse
@@ -37,7 +40,8 @@ ALGO_BYTES_PER_AUDIO_S = 4 * SR + 22 * (SR / HOP)
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense f32 matrix peak (v_mfma_f32_16x16x4_f32: 256 flop/cycle/CU x 256 CUs x 2.4 GHz)
 N_CUS = 256
-PMC_PROFILE = os.path.join("profiles", "r2_pmc_hbm.json")
+PMC_PROFILES = {"folder": os.path.join("profiles", "r3_pmc_hbm_folder.json"),
+                "shard": os.path.join("profiles", "r3_pmc_hbm_shard.json")}
 
 
 # --------------------------------------------------------------------------------------------- workloads
@@ -132,19 +136,24 @@ def cpu_baseline(sample_seconds, turbo_seconds, turbo_cores):
     return out
 
 
-def measured_traffic(kernel, default_workload):
-    """HBM bytes per step of `kernel` from the committed rocprofv3 --pmc passes of this command (FETCH_SIZE and
+def measured_traffic(kernel, workload):
+    """HBM bytes per step of `kernel` from the committed rocprofv3 --pmc passes of this workload (FETCH_SIZE and
     WRITE_SIZE in KB summed over one step's launches, FETCH_SIZE doubled per MI355X_MICROARCH.md).  A constant read
-    from the repository, not observed in this run: flagged `traffic_static`."""
-    path = os.path.join(ROOT, PMC_PROFILE)
-    if not default_workload or not os.path.exists(path):
-        return None, None
-    with open(path) as f:
+    from the repository, not observed in this run (`traffic_static`); the PMC passes serialise kernels, so they run the
+    schedule with one Viterbi launch per time chunk: the record carries that pass's own launch count."""
+    path = PMC_PROFILES.get(workload)
+    if path is None or not os.path.exists(os.path.join(ROOT, path)):
+        return None
+    with open(os.path.join(ROOT, path)) as f:
         pmc = json.load(f)
     rec = pmc.get("per_step", {}).get(kernel)
     if not rec:
-        return None, None
-    return int((2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024), PMC_PROFILE
+        return None
+    total = int((2 * rec["FETCH_SIZE_KB"] + rec["WRITE_SIZE_KB"]) * 1024)
+    return {"bytes_per_step": total, "source": path, "pmc_launches_per_step": rec.get("launches_per_step"),
+            "pmc_schedule": pmc.get("schedule", "AEGIS_VITERBI_PERSISTENT=0 (counter collection serialises kernels)"),
+            "whole_path_bytes_per_step": int(sum((2 * r["FETCH_SIZE_KB"] + r["WRITE_SIZE_KB"]) * 1024
+                                                 for r in pmc.get("per_step", {}).values()))}
 
 
 # --------------------------------------------------------------------------------------------- launcher
@@ -192,8 +201,8 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=("headline", "folder", "cqt"), default="headline")
-    ap.add_argument("--clips", type=int, default=64, help="headline: clips per GPU")
+    ap.add_argument("--config", choices=("folder", "shard", "headline", "cqt"), default="folder")
+    ap.add_argument("--clips", type=int, default=64, help="shard: clips per GPU")
     ap.add_argument("--clip-seconds", type=float, default=180.0)
     ap.add_argument("--folder-clips", type=int, default=512, help="folder: clips in the whole folder")
     ap.add_argument("--pass-frames", type=int, default=0, help="workspace bound in frames per pass (0 = the library's default)")
@@ -201,6 +210,8 @@ def parse_args():
     ap.add_argument("--cpu-turbo-seconds", type=float, default=120.0, help="oracle sample (B) Turbo Mode; 0 skips it")
     ap.add_argument("--cpu-turbo-cores", type=int, default=0, help="Turbo pool size; 0 = os.cpu_count() like the reference")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the uniform_shard / host_inclusive / engine_e2e sub-records (profiling runs)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="test hook: every rank uses cuda:0 and the gloo backend (multi-rank path on a 1-GPU box)")
     return ap.parse_args()
@@ -267,6 +278,8 @@ def run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum):
 
 def main():
     args = parse_args()
+    if args.config == "headline":
+        args.config = "shard"
     env_world = os.environ.get("WORLD_SIZE")
     if env_world is None and args.gpus > 1:
         sys.exit(launch_ranks(args.gpus))
@@ -349,39 +362,47 @@ def main():
     frame_counts = [handle.frames_for(int(n)) for n in n_samples]
     frames = int(sum(frame_counts))
 
-    d_pcm = torch.from_numpy(np.concatenate(clips) if clips else np.zeros(1, np.float32)).to(dev)
-    d_out = {
-        "f0": torch.empty(frames, dtype=torch.float64, device=dev),
-        "voiced_flag": torch.empty(frames, dtype=torch.uint8, device=dev),
-        "voiced_prob": torch.empty(frames, dtype=torch.float64, device=dev),
-        "rms": torch.empty(frames, dtype=torch.float32, device=dev),
-        "rake_mask": torch.empty(frames, dtype=torch.uint8, device=dev),
-    }
-    out_ptrs = {k: v.data_ptr() for k, v in d_out.items()}
-    del clips
+    d_pcm = torch.empty(max(1, int(offsets[-1])), dtype=torch.float32, device=dev)
+    for c, o in zip(clips, offsets[:-1]):          # clip by clip: no second host copy of the folder
+        d_pcm[int(o):int(o) + len(c)].copy_(torch.from_numpy(c))
 
-    def step():
-        handle.analyze_batch_device(d_pcm.data_ptr(), offsets, out_ptrs, rake_sensitivity=0.6,
-                                    stages=_lib.STAGE_ALL, sync=True)
+    def device_outputs(n_frames):
+        t = {"f0": torch.empty(n_frames, dtype=torch.float64, device=dev),
+             "voiced_flag": torch.empty(n_frames, dtype=torch.uint8, device=dev),
+             "voiced_prob": torch.empty(n_frames, dtype=torch.float64, device=dev),
+             "rms": torch.empty(n_frames, dtype=torch.float32, device=dev),
+             "rake_mask": torch.empty(n_frames, dtype=torch.uint8, device=dev)}
+        return t, {k: v.data_ptr() for k, v in t.items()}
 
-    for _ in range(args.warmup):
-        step()
-    handle.set_profiling(True)
-    handle.viterbi_stats(reset=True)
-    kernel_ms, kernel_n = {}, {}
+    d_out, out_ptrs = device_outputs(frames)
     KERNELS = ("frame", "pyin_obs", "viterbi", "finalize")
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        for k in KERNELS:
-            ms = handle.kernel_ms(k)
-            if ms >= 0:
-                kernel_ms[k] = kernel_ms.get(k, 0.0) + ms
-                kernel_n[k] = kernel_n.get(k, 0) + handle.kernel_launches(k)
-    busy = time.perf_counter() - t0          # this rank's own time, before it waits for the others
-    fence()
-    elapsed = time.perf_counter() - t0
+
+    def timed_steps(pcm_ptr, offs, ptrs, n_warm, n_steps, fenced=True):
+        """-> (seconds for n_steps between the fences, this rank's own seconds, per-kernel ms, per-kernel launches)"""
+        def step():
+            handle.analyze_batch_device(pcm_ptr, offs, ptrs, rake_sensitivity=0.6, stages=_lib.STAGE_ALL, sync=True)
+        handle.set_profiling(False)
+        for _ in range(n_warm):
+            step()
+        handle.set_profiling(True)
+        kms, kn = {}, {}
+        fence() if fenced else torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            step()
+            for k in KERNELS:
+                ms = handle.kernel_ms(k)
+                if ms >= 0:
+                    kms[k] = kms.get(k, 0.0) + ms
+                    kn[k] = kn.get(k, 0) + handle.kernel_launches(k)
+        own = time.perf_counter() - t0            # this rank's own time, before it waits for the others
+        fence() if fenced else torch.cuda.synchronize()
+        return time.perf_counter() - t0, own, kms, kn
+
+    handle.viterbi_stats(reset=True)
+    timed_steps(d_pcm.data_ptr(), offsets, out_ptrs, args.warmup, 0)
+    handle.viterbi_stats(reset=True)
+    elapsed, busy, kernel_ms, kernel_n = timed_steps(d_pcm.data_ptr(), offsets, out_ptrs, 0, args.steps)
     vstats = handle.viterbi_stats(reset=True)
     elapsed = reduce_max(elapsed)
     total_audio = reduce_sum(audio_seconds)
@@ -413,6 +434,57 @@ def main():
             assert len(set(gathered[:, 0].astype(int))) <= (args.folder_clips if args.config == "folder" else world * args.clips)
     events_ms = reduce_max(events_ms)
 
+    # ---- sub-records of the same run ("H2D included and reported separately") ----------------
+    host_inclusive = engine_e2e = uniform_shard = None
+    if not args.no_extras:
+        import io
+        from spectrogram_midi_amd.engine import AegisEngine
+        handle.set_profiling(False)
+        # (1) the host-buffer entry aegis_analyze_batch: pageable NumPy arrays in, NumPy arrays out (PCIe both ways)
+        for _ in range(2):                              # the first call sizes the staging buffers
+            fence()
+            t0 = time.perf_counter()
+            handle.analyze_batch(clips, rake_sensitivity=0.6, want_sdb=False)
+            dt_host = time.perf_counter() - t0
+            fence()
+        dt_host = reduce_max(dt_host)
+        host_inclusive = {"ms_per_step": round(dt_host * 1e3, 3), "value": round(total_audio / dt_host, 2),
+                          "unit": "audio-seconds/s", "entry": "aegis_analyze_batch (host float32 PCM in, host arrays out, per-clip dicts)"}
+        # (2) the reference-shaped surface: AegisEngine.analyze_arrays -> raw_data dicts -> extract_events -> SMF bytes
+        eng = AegisEngine(sample_rate=SR, hop_length=HOP, device=local_rank)
+        eng._handle = handle
+        fence()
+        t0 = time.perf_counter()
+        raws = eng.analyze_arrays(clips)
+        t1 = time.perf_counter()
+        midi_bytes = 0
+        for r in raws:
+            buf = io.BytesIO()
+            eng.extract_events(r, buf)
+            midi_bytes += buf.getbuffer().nbytes
+        t2 = time.perf_counter()
+        fence()
+        eng._handle = None
+        dt_an, dt_all = reduce_max(t1 - t0), reduce_max(t2 - t0)
+        engine_e2e = {"analyze_ms": round(dt_an * 1e3, 3), "audio_to_midi_ms": round(dt_all * 1e3, 3),
+                      "analyze_value": round(total_audio / dt_an, 2), "value": round(total_audio / dt_all, 2),
+                      "unit": "audio-seconds/s", "midi_bytes": int(reduce_sum(midi_bytes)),
+                      "entry": "AegisEngine.analyze_arrays + extract_events(raw, file-like) per clip (aegis_engine.py:41-181)"}
+        del raws
+        # (3) the uniform 64 x 180 s shard earlier rounds quoted, on this GPU alone
+        if args.config == "folder" and world == 1:
+            sclips = make_clips(64, 180.0, seed0=1)
+            soff = np.concatenate([[0], np.cumsum([len(c) for c in sclips])]).astype(np.int64)
+            d_spcm = torch.from_numpy(np.concatenate(sclips)).to(dev)
+            s_out, s_ptrs = device_outputs(int(sum(handle.frames_for(len(c)) for c in sclips)))
+            s_steps = 5
+            el, _, kms, _ = timed_steps(d_spcm.data_ptr(), soff, s_ptrs, 2, s_steps, fenced=False)
+            uniform_shard = {"workload": "64 clips x 180 s (configs[1] clip shape), device-resident, one GPU",
+                             "steps": s_steps, "ms_per_step": round(el / s_steps * 1e3, 3),
+                             "value": round(64 * 180.0 * s_steps / el, 2), "unit": "audio-seconds/s",
+                             "kernel_ms": {k: round(v / s_steps, 3) for k, v in kms.items()}}
+            del d_spcm, s_out, sclips
+
     line = None
     if rank == 0:
         kernel_ms = {k: v / args.steps for k, v in kernel_ms.items()}
@@ -420,8 +492,10 @@ def main():
         dom_ms = kernel_ms[dom]
         achieved = ALGO_BYTES_PER_AUDIO_S * audio_seconds / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         launches = max(1, kernel_n.get(dom, 0) // max(1, args.steps))
-        default_workload = args.config == "headline" and args.clips == 64 and args.clip_seconds == 180.0
-        traffic, traffic_src = measured_traffic(dom, default_workload)
+        default_workload = (args.config == "folder" and args.folder_clips == 512 and world == 1) or \
+                           (args.config == "shard" and args.clips == 64 and args.clip_seconds == 180.0)
+        pmc = measured_traffic(dom, args.config) if default_workload else None
+        traffic = None if pmc is None else pmc["bytes_per_step"]
         voiced = float(d_out["voiced_flag"].float().mean().item())
         if args.config == "folder":
             workload = (f"configs[3] as written: folder of {args.folder_clips} clips, durations U(30,330) s (1/8 polyphonic, 1/8 noisy), "
@@ -430,7 +504,7 @@ def main():
                    "folder_audio_seconds": round(total_audio, 1)}
             scaling = "strong"
         else:
-            workload = (f"configs[3] per-GPU shard: {args.clips} clips x {args.clip_seconds:g} s "
+            workload = (f"configs[3] per-GPU shard (uniform lengths): {args.clips} clips x {args.clip_seconds:g} s "
                         "(configs[1] clip shape), full mel/dB/rake + pYIN + RMS")
             cfg = {"workload": workload, "clips_per_gpu": args.clips, "clip_seconds": args.clip_seconds}
             scaling = "weak"
@@ -450,14 +524,19 @@ def main():
             "config": cfg,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "traffic_static": traffic is not None, "traffic_source": traffic_src,
+                         "traffic_static": traffic is not None, "traffic_source": None if pmc is None else pmc["source"],
+                         "traffic_pmc_launches_per_step": None if pmc is None else pmc["pmc_launches_per_step"],
+                         "traffic_pmc_schedule": None if pmc is None else pmc["pmc_schedule"],
+                         "traffic_whole_path": None if pmc is None else pmc["whole_path_bytes_per_step"],
                          # the time-chunked pipeline launches the kernel once per time chunk: bytes and
                          # duration below are per step (= sum over those launches); avg_launch_ms is what
                          # rocprofv3 --stats reports as AverageNs
                          "launches_per_step": launches, "avg_launch_ms": round(dom_ms / launches, 3),
                          "algorithmic_bytes_per_step": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds),
                          "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_AUDIO_S * audio_seconds / launches),
-                         "traffic_per_launch": None if traffic is None else int(traffic / launches),
+                         # per launch of the PMC pass's own schedule (the live schedule may launch differently)
+                         "traffic_per_launch": None if (pmc is None or not pmc["pmc_launches_per_step"]) else
+                                               int(traffic / pmc["pmc_launches_per_step"]),
                          # why the HBM fraction is small: the time-sequential Viterbi occupies one CU per clip
                          # (up to 64 clips the library partitions the CUs: 64 for the Viterbi, 192 for the frame stage)
                          "cus_busy_fraction": round(clips_in_flight / N_CUS, 4) if dom == "viterbi"
@@ -469,6 +548,7 @@ def main():
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                        "backend": None if world == 1 else ("gloo" if args.rehearse_on_one_gpu else "nccl (RCCL)")},
         }
+        line["uniform_shard"], line["host_inclusive"], line["engine_e2e"] = uniform_shard, host_inclusive, engine_e2e
         if vstats is not None and vstats["wave_steps"] > 0:
             line["viterbi_list_only_rate"] = round(vstats["list_only"] / max(1, vstats["wave_steps"] - vstats["skipped"]), 5)
             # voiced waves whose 64 targets are all dead at an easy frame skip the step (exact: viterbi.hip)

@@ -34,6 +34,12 @@ def test_parent_launcher_does_not_import_torch_and_propagates_failure():
 
 
 def test_folder_workload_matches_configs3():
+    argv, sys.argv = sys.argv, ["bench.py"]
+    try:
+        a = bench.parse_args()
+    finally:
+        sys.argv = argv
+    assert a.config == "folder" and a.folder_clips == 512 and a.gpus == 1      # the driver's bare run = configs[3] as written
     d = bench.folder_durations(512)
     assert len(d) == 512 and d.min() >= 30 and d.max() <= 330 and abs(d.mean() - 180) < 10
     np.testing.assert_array_equal(d, bench.folder_durations(512))        # seeded
@@ -49,8 +55,8 @@ def test_folder_workload_matches_configs3():
 
 @pytest.mark.gpu
 def test_bare_gpus_2_runs_two_ranks_and_gathers_events():
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--clips", "3",
-           "--clip-seconds", "8", "--no-cpu-baseline", "--rehearse-on-one-gpu"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--config", "shard",
+           "--clips", "3", "--clip-seconds", "8", "--no-cpu-baseline", "--rehearse-on-one-gpu"]
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -60,6 +66,9 @@ def test_bare_gpus_2_runs_two_ranks_and_gathers_events():
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and len(line["rank_busy_ms"]) == 2
     assert line["events"]["backend"] == "gloo" and line["events"]["gather_ms"] is not None and line["events"]["count"] > 0
     assert abs(sum(line["rank_audio_seconds"]) - 2 * 3 * 8) < 0.1
+    # sub-records of the same run: the host-buffer entry and the engine surface, whole-job rates
+    assert line["host_inclusive"]["value"] > 0 and line["engine_e2e"]["value"] > 0 and line["engine_e2e"]["midi_bytes"] > 0
+    assert line["engine_e2e"]["audio_to_midi_ms"] >= line["engine_e2e"]["analyze_ms"] and line["uniform_shard"] is None
 
 
 @pytest.mark.gpu
@@ -74,3 +83,4 @@ def test_folder_mode_two_ranks():
     assert line["n_gpus"] == 2 and line["scaling"] == "strong"
     assert abs(line["config"]["folder_audio_seconds"] - float(np.floor(d * 44100).sum() / 44100)) < 0.1
     assert 0.0 <= line.get("viterbi_list_only_rate", 0.5) <= 1.0
+    assert "folder of 6 clips" in line["config"]["workload"] and line["host_inclusive"]["value"] > 0

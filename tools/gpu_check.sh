@@ -9,7 +9,7 @@ timeout -k 10 900 python -m pytest tests -m gpu -x -q > $O/gputests.log 2>&1; ec
 grep -q "pytest rc=0" $O/gputests.log || exit 1
 run() {
   n=$1; shift
-  env "$@" "${EXTRA_ENV[@]}" timeout -k 10 400 python bench.py $BARGS --no-cpu-baseline > $O/bench_$n.log 2>&1 || { echo "$n failed"; tail -5 $O/bench_$n.log; return 1; }
+  env "$@" "${EXTRA_ENV[@]}" timeout -k 10 400 python bench.py $BARGS --no-cpu-baseline --no-extras > $O/bench_$n.log 2>&1 || { echo "$n failed"; tail -5 $O/bench_$n.log; return 1; }
   python - <<PY
 import json
 l=[x for x in open("$O/bench_$n.log") if x.startswith("{")][-1]; d=json.loads(l)
@@ -17,9 +17,9 @@ print("$n", d["ms_per_step"], d["value"], d["roofline"]["kernel_ms"], d.get("vit
 PY
 }
 EXTRA_ENV=("$@"); [ ${#EXTRA_ENV[@]} -eq 0 ] && EXTRA_ENV=(AEGIS_X=0)
-BARGS="--steps 8 --warmup 2"
+BARGS="--config shard --steps 8 --warmup 2"
 run c64 AEGIS_X=0; run c64_1chunk AEGIS_BALANCED_CHUNK=0 AEGIS_TIME_CHUNK=65536
-BARGS="--steps 3 --warmup 1 --clips 256"
+BARGS="--config shard --steps 3 --warmup 1 --clips 256"
 run c256 AEGIS_X=0
 BARGS="--steps 2 --warmup 1 --config folder"
 run folder AEGIS_X=0
