@@ -340,7 +340,7 @@ def main():
     if args.config == "cqt":
         return finish(run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum))
 
-    from spectrogram_midi_amd import _lib, dist as adist, midi_logic
+    from spectrogram_midi_amd import _lib, dist as adist, events_native
 
     # ---- this rank's clips ---------------------------------------------------------------------------
     if args.config == "folder":
@@ -371,7 +371,8 @@ def main():
              "voiced_flag": torch.empty(n_frames, dtype=torch.uint8, device=dev),
              "voiced_prob": torch.empty(n_frames, dtype=torch.float64, device=dev),
              "rms": torch.empty(n_frames, dtype=torch.float32, device=dev),
-             "rake_mask": torch.empty(n_frames, dtype=torch.uint8, device=dev)}
+             "rake_mask": torch.empty(n_frames, dtype=torch.uint8, device=dev),
+             "pitch_bin": torch.empty(n_frames, dtype=torch.int16, device=dev)}
         return t, {k: v.data_ptr() for k, v in t.items()}
 
     d_out, out_ptrs = device_outputs(frames)
@@ -412,15 +413,11 @@ def main():
     # ---- note events of this rank's clips, gathered on rank 0 (the only exchange of the job) -----------
     t0 = time.perf_counter()
     host = {k: v.cpu().numpy() for k, v in d_out.items()}
-    rows, fo = [], 0
-    for cid, Fc in zip(clip_ids, frame_counts):
-        sl = slice(fo, fo + Fc)
-        ev = midi_logic.get_midi_events(rake_mask=host["rake_mask"][sl].astype(bool), f0=np.nan_to_num(host["f0"][sl]),
-                                        voiced_flag=host["voiced_flag"][sl].astype(bool), active_probs=host["voiced_prob"][sl],
-                                        rms=host["rms"][sl], sr=SR, hop_length=HOP, confidence_threshold=0.70)
-        rows.append(adist.pack_events(cid, ev))
-        fo += Fc
-    local_rows = np.concatenate(rows) if rows else np.zeros((0, 10))
+    f_off = np.concatenate([[0], np.cumsum(frame_counts)]).astype(np.int64)
+    ev_packed, _ = events_native.extract_batch(f_off, host["rake_mask"], host["f0"], host["voiced_flag"],
+                                               host["voiced_prob"], host["rms"], SR, HOP, 0.70, packed=True,
+                                               pitch_bin=host["pitch_bin"], freqs=handle.table("freqs"))
+    local_rows = adist.rows_from_packed(ev_packed, clip_ids)
     events_ms = (time.perf_counter() - t0) * 1e3
     gather_ms, n_events = None, int(local_rows.shape[0])
     if world > 1:
@@ -450,26 +447,33 @@ def main():
         dt_host = reduce_max(dt_host)
         host_inclusive = {"ms_per_step": round(dt_host * 1e3, 3), "value": round(total_audio / dt_host, 2),
                           "unit": "audio-seconds/s", "entry": "aegis_analyze_batch (host float32 PCM in, host arrays out, per-clip dicts)"}
-        # (2) the reference-shaped surface: AegisEngine.analyze_arrays -> raw_data dicts -> extract_events -> SMF bytes
+        # (2) the reference-shaped surface.  Batch form: AegisEngine.audio_to_midi_batch = analyze_arrays (one GPU batch) +
+        # one batched event extraction and SMF rendering; per-clip form: extract_events(raw, file-like) clip by clip
         eng = AegisEngine(sample_rate=SR, hop_length=HOP, device=local_rank)
         eng._handle = handle
         fence()
         t0 = time.perf_counter()
+        raws, evs, blobs = eng.audio_to_midi_batch(clips)
+        dt_batch = time.perf_counter() - t0
+        fence()
+        midi_bytes = sum(len(b) for b in blobs if b is not None)
+        del evs, blobs
+        fence()
+        t0 = time.perf_counter()
         raws = eng.analyze_arrays(clips)
         t1 = time.perf_counter()
-        midi_bytes = 0
         for r in raws:
-            buf = io.BytesIO()
-            eng.extract_events(r, buf)
-            midi_bytes += buf.getbuffer().nbytes
+            eng.extract_events(r, io.BytesIO())
         t2 = time.perf_counter()
         fence()
         eng._handle = None
-        dt_an, dt_all = reduce_max(t1 - t0), reduce_max(t2 - t0)
-        engine_e2e = {"analyze_ms": round(dt_an * 1e3, 3), "audio_to_midi_ms": round(dt_all * 1e3, 3),
-                      "analyze_value": round(total_audio / dt_an, 2), "value": round(total_audio / dt_all, 2),
+        dt_batch, dt_an, dt_all = reduce_max(dt_batch), reduce_max(t1 - t0), reduce_max(t2 - t0)
+        engine_e2e = {"audio_to_midi_ms": round(dt_batch * 1e3, 3), "value": round(total_audio / dt_batch, 2),
                       "unit": "audio-seconds/s", "midi_bytes": int(reduce_sum(midi_bytes)),
-                      "entry": "AegisEngine.analyze_arrays + extract_events(raw, file-like) per clip (aegis_engine.py:41-181)"}
+                      "entry": "AegisEngine.audio_to_midi_batch(clips): raw_data dicts + events + SMF bytes of every clip (aegis_engine.py:41-181)",
+                      "per_clip_api": {"analyze_ms": round(dt_an * 1e3, 3), "audio_to_midi_ms": round(dt_all * 1e3, 3),
+                                       "analyze_value": round(total_audio / dt_an, 2), "value": round(total_audio / dt_all, 2),
+                                       "entry": "AegisEngine.analyze_arrays + extract_events(raw, file-like) per clip"}}
         del raws
         # (3) the uniform 64 x 180 s shard earlier rounds quoted, on this GPU alone
         if args.config == "folder" and world == 1:

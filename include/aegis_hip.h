@@ -37,6 +37,12 @@ extern "C" {
 #define AEGIS_STAGE_PYIN 0x4  /* f0 / voiced / voiced_prob  aegis_engine.py:63,67, worker.py:9-15 */
 #define AEGIS_STAGE_RMS 0x8   /* frame RMS                  aegis_engine.py:70 */
 #define AEGIS_STAGE_ALL 0xF
+/* options carried in the same bitmask */
+#define AEGIS_OPT_CHECK_FINITE 0x10 /* librosa.util.valid_audio (inside librosa.load / pyin): a NaN or infinite sample makes
+                                       the call fail with AEGIS_ERR_INVALID, "Audio buffer is not finite everywhere (clip N)".
+                                       Checked on the device, where every sample is read anyway; blocking calls only
+                                       (aegis_analyze_batch, aegis_analyze_batch_device with sync != 0) */
+#define AEGIS_OPT_F0_ZERO 0x20      /* unvoiced f0 = 0.0 instead of NaN: np.nan_to_num(f0), aegis_engine.py:69 */
 
 typedef struct aegis_handle aegis_handle;
 
@@ -75,6 +81,8 @@ typedef struct aegis_outputs {
     float *rms;           /* [F_total] */
     uint8_t *rake_mask;   /* [F_total]  0/1 */
     float *S_dB;          /* per clip [n_mels, F_clip] C-order, clip after clip (n_mels*F_total) */
+    int16_t *pitch_bin;   /* [F_total]  the decoded pitch bin (f0 == freqs[bin], aegis_get_table "freqs"), -1 where unvoiced:
+                             lets the event logic take hz_to_midi(f0) from a table of n_pitch_bins entries */
 } aegis_outputs;
 
 int aegis_abi_version(void);
@@ -174,6 +182,66 @@ void aegis_stream_free(aegis_stream *st);
 #define AEGIS_TREND_CONSENSUS 11
 int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
                 const double *params, int32_t n_params, void *const *outs, int32_t n_outs);
+
+/* --- note events and Standard MIDI Files for a batch of clips: host code, no GPU, no handle ----------------
+ * SURVEY.md 8(f) rank 1.  aegis_extract_events replaces get_midi_events + detect_articulations
+ * (aegis_engine_core/midi_logic.py:32-148, 6-30) from the point where the frame arrays are gated: the caller passes,
+ * concatenated clip after clip (clip c = frames frame_off[c] .. frame_off[c+1]),
+ *   sounding   u8   voiced_flag & ~(rms_db < noise_gate_db) & (f0 > 0) & ~rake_mask          (midi_logic.py:62-68)
+ *   semitones  f64  librosa.hz_to_midi(f0) on the sounding frames (anything elsewhere)      (midi_logic.py:69)
+ *              -- or NULL, with pitch_bin i16 (aegis_outputs.pitch_bin) and bin_semitones f64[n_pitch_bins] =
+ *              hz_to_midi(freqs): the same values without a logarithm per frame
+ *   rms_db     f32  librosa.amplitude_to_db(rms, ref=np.max) of the clip                    (midi_logic.py:51)
+ *   probs      f64  voiced_probs
+ * (the two logarithms stay with NumPy, whose float32 log10 / float64 log2 kernels are not libm's: the Python binding
+ * spectrogram-midi_amd/events_native.py prepares them for a whole batch in a handful of array calls).  Events come back
+ * clip after clip; clip_event_off[n_clips + 1] delimits them.  A note whose articulation decision lies within 1e-9 of one
+ * of the reference's thresholds (pitch tracks sit on a 0.1-semitone grid: exact ties occur) is not decided here: such
+ * runs are listed in risky_runs (clip, start, end), their clips produce no events, and the caller calls again with the
+ * reference's own verdicts for them in batch->fits (detect_articulations through np.polyfit, midi_logic.py:6-30).
+ * Returns the number of events (which may exceed cap: nothing past cap is written) or a negative code;
+ * aegis_events_last_error() has the message (thread-local).
+ * aegis_render_smf replaces the SMF block of AegisEngine.extract_events (aegis_engine.py:98-179, mido's writer: type 1,
+ * 480 ticks per beat, two tracks main / safe, running status, end_of_track): one file per clip, concatenated in `out`,
+ * clip_byte_off[n_clips + 1] delimits them; returns the total size (which may exceed cap: then nothing is complete). */
+typedef struct aegis_event {
+    int32_t clip, note, start, end, velocity; /* start / end: inclusive frame indices (midi_logic.py:74-79) */
+    uint8_t track;                            /* 1 'main', 0 'safe' */
+    uint8_t technique;                        /* 0 None 1 vibrato 2 bend 3 slide 4 hammer_on 5 pull_off */
+    uint8_t reserved0, reserved1;
+    float rms_energy;                         /* dB, the note's first frame */
+    int32_t reserved2;
+    double confidence, slope;
+} aegis_event;
+typedef struct aegis_event_params {
+    int32_t sample_rate, hop_length;
+    double confidence_threshold;              /* 0.70  aegis_engine.py:85 */
+    double sustain_ms, min_note_duration_ms;  /* 50, 50  midi_logic.py:37-38 (the noise gate is applied by the caller) */
+} aegis_event_params;
+typedef struct aegis_run_fit {                /* one note-run and, in aegis_event_batch.fits, its articulation verdict */
+    int32_t clip, start, end;                 /* frames start..end inclusive */
+    int32_t technique;                        /* 0 None 1 vibrato 2 bend 3 slide */
+    double slope;
+} aegis_run_fit;
+typedef struct aegis_event_batch {
+    int32_t n_clips;
+    int32_t reserved;
+    const int64_t *frame_off;                 /* [n_clips + 1] */
+    const uint8_t *sounding;
+    const double *semitones;                  /* or NULL with the next two */
+    const int16_t *pitch_bin;
+    const double *bin_semitones;
+    const float *rms_db;
+    const double *probs;
+    const aegis_run_fit *fits;                /* verdicts for runs an earlier call listed as risky, sorted by (clip, start); may be NULL */
+    int64_t n_fits;
+} aegis_event_batch;
+int64_t aegis_extract_events(const aegis_event_params *params, const aegis_event_batch *batch, aegis_event *events, int64_t cap,
+                             int64_t *clip_event_off, aegis_run_fit *risky_runs, int64_t risky_cap, int64_t *n_risky);
+int64_t aegis_render_smf(int32_t sample_rate, int32_t hop_length, int32_t midi_program, double vibrato_rate,
+                         double vibrato_depth, int32_t n_clips, const aegis_event *events, const int64_t *clip_event_off,
+                         uint8_t *out, int64_t cap, int64_t *clip_byte_off);
+const char *aegis_events_last_error(void);
 
 /* --- introspection used by the tests (no reference counterpart) ------------- */
 

@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AEGIS_HIP_LIB", os.path.join(_HERE, "libaegis_hip.so"))
 
 STAGE_MEL, STAGE_RAKE, STAGE_PYIN, STAGE_RMS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
+OPT_CHECK_FINITE, OPT_F0_ZERO = 0x10, 0x20
 (TREND_SMA, TREND_EMA, TREND_BOLLINGER, TREND_ARTICULATION, TREND_MACD, TREND_SLIDES, TREND_RSI, TREND_SAVGOL,
  TREND_KALMAN, TREND_HOLT, TREND_CONSENSUS) = range(1, 12)
 OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95
@@ -34,13 +35,14 @@ class StreamFrames(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [("f0", C.c_void_p), ("voiced_flag", C.c_void_p), ("voiced_prob", C.c_void_p),
-                ("rms", C.c_void_p), ("rake_mask", C.c_void_p), ("S_dB", C.c_void_p)]
+                ("rms", C.c_void_p), ("rake_mask", C.c_void_p), ("S_dB", C.c_void_p), ("pitch_bin", C.c_void_p)]
 
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
            "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend",
-           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt")
+           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt",
+           "aegis_extract_events", "aegis_render_smf", "aegis_events_last_error")
 
 _lib = None
 
@@ -209,16 +211,20 @@ class Handle:
             return None
         return {"wave_steps": int(v[0]), "list_only": int(v[1]), "skipped": int(v[2])}
 
-    def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True):
+    def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True, check_finite=False,
+                      f0_zero=False, views=False, concatenated=False):
         """clips: list of float32 1-D arrays (host).  Returns a list of per-clip dicts with the
-        dtypes of the reference's raw_data (aegis_engine.py:72-75); f0 keeps NaN where unvoiced."""
+        dtypes of the reference's raw_data (aegis_engine.py:72-75); f0 keeps NaN where unvoiced unless f0_zero
+        (np.nan_to_num, aegis_engine.py:69).  check_finite: librosa's valid_audio test on the device -> ValueError.
+        views: the per-clip arrays are slices of the batch's buffers instead of copies.  concatenated: also return
+        (buffers dict, frame offsets) of the whole batch, for the batched event extraction."""
         clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
         n = len(clips)
         if n == 0:
-            return []
+            return ([], {}, np.zeros(1, np.int64)) if concatenated else []
         ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in clips])
         lens = (C.c_int64 * n)(*[len(c) for c in clips])
-        frames = [self.frames_for(len(c)) for c in clips]
+        frames = [1 + len(c) // self.hop for c in clips]
         F = sum(frames)
         if stages & STAGE_RAKE:
             stages |= STAGE_MEL
@@ -228,6 +234,8 @@ class Handle:
             bufs["f0"] = np.empty(F, np.float64)
             bufs["voiced_flag"] = np.empty(F, np.uint8)
             bufs["voiced_prob"] = np.empty(F, np.float64)
+            if concatenated:
+                bufs["pitch_bin"] = np.empty(F, np.int16)     # batch-level only: not part of the per-clip dicts
         if stages & STAGE_RMS:
             bufs["rms"] = np.empty(F, np.float32)
         if stages & STAGE_RAKE:
@@ -236,20 +244,31 @@ class Handle:
             bufs["S_dB"] = np.empty(F * self.n_mels, np.float32)
         for k, v in bufs.items():
             setattr(out, k, v.ctypes.data)
-        self._check(self.lib.aegis_analyze_batch(self._h, ptrs, lens, n, float(rake_sensitivity),
-                                                 int(stages), C.byref(out)))
+        flags = int(stages) | (OPT_CHECK_FINITE if check_finite else 0) | (OPT_F0_ZERO if f0_zero else 0)
+        rc = self.lib.aegis_analyze_batch(self._h, ptrs, lens, n, float(rake_sensitivity), flags, C.byref(out))
+        if rc == ERR_INVALID and check_finite:
+            msg = self.lib.aegis_last_error(self._h).decode()
+            if msg.startswith("Audio buffer is not finite"):
+                raise ValueError(msg)                       # librosa.util.valid_audio's ParameterError
+        self._check(rc)
+        for k in ("voiced_flag", "rake_mask"):              # 0 / 1 bytes: the same memory read as bool
+            if k in bufs:
+                bufs[k] = bufs[k].view(bool)
         res, fo = [], 0
-        for c, Fc in zip(clips, frames):
+        for Fc in frames:
             d = {}
             for k, v in bufs.items():
+                if k == "pitch_bin":
+                    continue
                 if k == "S_dB":
-                    d[k] = v[fo * self.n_mels:(fo + Fc) * self.n_mels].reshape(self.n_mels, Fc).copy()
-                elif k in ("voiced_flag", "rake_mask"):
-                    d[k] = v[fo:fo + Fc].astype(bool)
+                    a = v[fo * self.n_mels:(fo + Fc) * self.n_mels].reshape(self.n_mels, Fc)
                 else:
-                    d[k] = v[fo:fo + Fc].copy()
+                    a = v[fo:fo + Fc]
+                d[k] = a if views else a.copy()
             res.append(d)
             fo += Fc
+        if concatenated:
+            return res, bufs, np.concatenate([[0], np.cumsum(frames)]).astype(np.int64)
         return res
 
     def rake_patterns(self, S_dB, ratio):

@@ -72,7 +72,7 @@ struct aegis_handle {
         DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate, chunk_lo, chunk_flag;
     } work[2];
     int last_work = 0;
-    DevBuf vstats, rk_raw, abort_flag;
+    DevBuf vstats, rk_raw, abort_flag, finite_flag;
     uint32_t chunk_gen = 0;                   // generation of the chunk flags of a persistent Viterbi launch
     int test_drop_signal = -1;
     bool persist_gave_up = false;
@@ -82,7 +82,7 @@ struct aegis_handle {
     CqtBank cqt_bank;
     DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
-    DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb;
+    DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb, io_bin;
     int32_t lag_stride = 0, yin_stride = 0, obs_stride = 0;
     std::vector<PassMeta> metas;
     // last pass geometry for aegis_debug_fetch
@@ -167,6 +167,7 @@ PassParams base_params(const Tables &t) {
     p.sr = t.sr; p.hop = t.hop; p.n_mels = t.n_mels;
     p.min_period = t.min_period; p.max_period = t.max_period; p.n_lags = t.n_lags;
     p.n_bins = t.n_bins; p.half_width = t.half_width; p.width = t.width; p.n_cls = t.n_cls;
+    p.f0_unvoiced = NAN;
     p.fmin = t.fmin; p.log_tiny = t.log_tiny; p.log_pinit_v = t.log_pinit[0]; p.log_pinit_u = t.log_pinit[1];
     return p;
 }
@@ -356,9 +357,9 @@ static void destroy_now(aegis_handle *h) noexcept {
                           &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
                           &w.vstate, &w.chunk_lo, &w.chunk_flag})
             free_buf(*b);
-    for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
+    for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->finite_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
-                      &h->io_sdb})
+                      &h->io_sdb, &h->io_bin})
         free_buf(*b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -446,6 +447,19 @@ static int persistent_check(aegis_handle *h) {
     return AEGIS_OK;
 }
 
+// After a synchronisation: the verdict of AEGIS_OPT_CHECK_FINITE (librosa.util.valid_audio's ParameterError).
+static int finite_result(aegis_handle *h, uint32_t opts, const int64_t *sample_offsets, int32_t n_clips) {
+    if (!(opts & AEGIS_OPT_CHECK_FINITE) || !h->finite_flag.p) return AEGIS_OK;
+    unsigned long long bad = ~0ull;
+    HIPCHK(h, hipMemcpy(&bad, h->finite_flag.p, 8, hipMemcpyDeviceToHost));
+    if (bad == ~0ull) return AEGIS_OK;
+    const int64_t idx = sample_offsets[0] + (int64_t)bad;
+    int clip = 0;
+    while (clip + 1 < n_clips && sample_offsets[clip + 1] <= idx) ++clip;
+    h->err = "Audio buffer is not finite everywhere (clip " + std::to_string(clip) + ", sample " + std::to_string(idx - sample_offsets[clip]) + ")";
+    return AEGIS_ERR_INVALID;
+}
+
 static aegis_handle::SplitSet *split_streams(aegis_handle *h, int n_clips) {
     if (n_clips > h->split_limit || h->split_limit <= 0) return nullptr;
     if (h->n_cus != 256) return nullptr;      // the masks below are laid out for the 256 CUs of an un-partitioned MI355X
@@ -483,6 +497,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     if (n_clips < 0 || (n_clips > 0 && (!sample_offsets || !dout))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
     if (n_clips == 0) return AEGIS_OK;
     if (stages & AEGIS_STAGE_RAKE) stages |= AEGIS_STAGE_MEL;
+    const uint32_t opts = stages & (AEGIS_OPT_CHECK_FINITE | AEGIS_OPT_F0_ZERO);
     stages &= AEGIS_STAGE_ALL;
     const Tables &t = h->tab;
     if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
@@ -723,11 +738,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.out_f0 = py ? dout->f0 : nullptr;
         p.out_voiced = py ? dout->voiced_flag : nullptr;
         p.out_vprob = py ? dout->voiced_prob : nullptr;
+        p.out_bin = py ? dout->pitch_bin : nullptr;
         p.out_rms = (stages & AEGIS_STAGE_RMS) ? dout->rms : nullptr;
         p.out_rake = (stages & AEGIS_STAGE_RAKE) ? dout->rake_mask : nullptr;
         p.out_sdb = (stages & AEGIS_STAGE_MEL) ? dout->S_dB : nullptr;
         p.rake_ratio = rake_sensitivity;
         p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
+        if (opts & AEGIS_OPT_F0_ZERO) p.f0_unvoiced = 0.0;
 
         if (persistent) {
             p.chunk_flag = static_cast<const uint32_t *>(w.chunk_flag.p);
@@ -815,11 +832,20 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     // the caller's stream continues after everything enqueued above
     for (int q = 0; q < 2; ++q)
         if (done_recorded[q]) HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[EV_DONE0 + q], 0));
+    if (opts & AEGIS_OPT_CHECK_FINITE) {       // behind the last sample copy of a host feed: every sample is on the device by now
+        int rc;
+        if ((rc = ensure(h, h->finite_flag, 8)) != AEGIS_OK) return rc;
+        HIPCHK(h, hipMemsetAsync(h->finite_flag.p, 0xff, 8, s));
+        const int64_t lo = sample_offsets[0], hi = sample_offsets[n_clips];
+        launch_finite_check(d_pcm + lo, hi - lo, static_cast<unsigned long long *>(h->finite_flag.p), s);
+    }
     if (sync) {
         HIPCHK(h, hipStreamSynchronize(s));
         h->metas.clear();
         if (h->profiling) collect_events(h);
-        return persistent_check(h);
+        int rc = persistent_check(h);
+        if (rc != AEGIS_OK) return rc;
+        return finite_result(h, opts, sample_offsets, n_clips);
     }
     return AEGIS_OK;
 }
@@ -851,6 +877,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     const int nm = h->tab.n_mels;
     if ((stages & AEGIS_STAGE_PYIN) && out->f0) { if ((rc = ensure(h, h->io_f0, F * 8))) return rc; d.f0 = static_cast<double *>(h->io_f0.p); }
     if ((stages & AEGIS_STAGE_PYIN) && out->voiced_flag) { if ((rc = ensure(h, h->io_voiced, F))) return rc; d.voiced_flag = static_cast<uint8_t *>(h->io_voiced.p); }
+    if ((stages & AEGIS_STAGE_PYIN) && out->pitch_bin) { if ((rc = ensure(h, h->io_bin, F * 2))) return rc; d.pitch_bin = static_cast<int16_t *>(h->io_bin.p); }
     if ((stages & AEGIS_STAGE_PYIN) && out->voiced_prob) { if ((rc = ensure(h, h->io_vprob, F * 8))) return rc; d.voiced_prob = static_cast<double *>(h->io_vprob.p); }
     if ((stages & AEGIS_STAGE_RMS) && out->rms) { if ((rc = ensure(h, h->io_rms, F * 4))) return rc; d.rms = static_cast<float *>(h->io_rms.p); }
     if ((stages & AEGIS_STAGE_RAKE) && out->rake_mask) { if ((rc = ensure(h, h->io_rake, F))) return rc; d.rake_mask = static_cast<uint8_t *>(h->io_rake.p); }
@@ -860,6 +887,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if (rc != AEGIS_OK) return rc;
     if (d.f0) HIPCHK(h, hipMemcpyAsync(out->f0, d.f0, F * 8, hipMemcpyDeviceToHost, s));
     if (d.voiced_flag) HIPCHK(h, hipMemcpyAsync(out->voiced_flag, d.voiced_flag, F, hipMemcpyDeviceToHost, s));
+    if (d.pitch_bin) HIPCHK(h, hipMemcpyAsync(out->pitch_bin, d.pitch_bin, F * 2, hipMemcpyDeviceToHost, s));
     if (d.voiced_prob) HIPCHK(h, hipMemcpyAsync(out->voiced_prob, d.voiced_prob, F * 8, hipMemcpyDeviceToHost, s));
     if (d.rms) HIPCHK(h, hipMemcpyAsync(out->rms, d.rms, F * 4, hipMemcpyDeviceToHost, s));
     if (d.rake_mask) HIPCHK(h, hipMemcpyAsync(out->rake_mask, d.rake_mask, F, hipMemcpyDeviceToHost, s));
@@ -868,7 +896,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     h->metas.clear();
     if ((rc = persistent_check(h)) != AEGIS_OK) return rc;
     if (h->profiling) collect_events(h);
-    return AEGIS_OK;
+    return finite_result(h, stages, off.data(), n_clips);
     } catch (...) { return abi_fail(h); }
 }
 

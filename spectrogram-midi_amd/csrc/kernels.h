@@ -95,8 +95,10 @@ struct PassParams {
     // outputs of the whole call, indexed through out_off (may be null)
     double *out_f0; uint8_t *out_voiced; double *out_vprob; float *out_rms;
     uint8_t *out_rake; float *out_sdb;   // clip c's dB image starts at n_mels * out_off[c]
+    int16_t *out_bin;                    // decoded pitch bin, -1 unvoiced
     double rake_ratio;
     int32_t rake_min_frames, rake_max_frames;
+    double f0_unvoiced;                  // what an unvoiced frame's f0 reads: NaN (librosa.pyin fill_na) or 0.0 (np.nan_to_num)
 };
 
 constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
@@ -107,6 +109,8 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
 bool viterbi_band_applies(const PassParams &p, const DevTables &t);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry
 void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s);
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);
+// first_bad (device, preset to ~0): smallest index of a sample of pcm[0..n) that is NaN or infinite
+void launch_finite_check(const float *pcm, int64_t n, unsigned long long *first_bad, hipStream_t s);
 void launch_finalize_mel(const PassParams &p, const DevTables &t, hipStream_t s);
 void launch_rake_from_db(const float *sdb, int n_mels, int64_t F, double ratio, int min_frames, int max_frames,
                          uint8_t *raw, uint8_t *out, hipStream_t s);

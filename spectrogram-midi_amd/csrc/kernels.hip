@@ -932,7 +932,8 @@ __global__ __launch_bounds__(256) void decode_kernel(PassParams p, DevTables tb)
     const int c = find_clip(p.frame_off, p.n_clips, f);
     const int64_t fo = out_index(p, c, f - p.frame_off[c]);
     if (p.out_voiced != nullptr) p.out_voiced[fo] = voiced ? 1 : 0;
-    if (p.out_f0 != nullptr) p.out_f0[fo] = voiced ? tb.freqs[s] : (double)NAN;
+    if (p.out_f0 != nullptr) p.out_f0[fo] = voiced ? tb.freqs[s] : p.f0_unvoiced;
+    if (p.out_bin != nullptr) p.out_bin[fo] = voiced ? (int16_t)s : (int16_t)-1;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1149,6 +1150,22 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     const size_t lds = (size_t)(TN + waves * (YN + UN)) * 8;
     const int64_t per_wg = (int64_t)waves * fpw;
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)((p.n_sel + per_wg - 1) / per_wg)), dim3(64 * waves), lds, s, p, t, fpw);
+}
+// librosa.util.valid_audio: every sample finite.  16 bytes per thread and iteration, one atomic per wave that finds one.
+__global__ __launch_bounds__(256) void finite_check_kernel(const float *__restrict__ pcm, int64_t n, unsigned long long *first_bad) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    unsigned long long bad = ~0ull;
+    for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += stride) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (i + k < n && (__float_as_uint(pcm[i + k]) & 0x7f800000u) == 0x7f800000u) bad = min(bad, (unsigned long long)(i + k));
+    }
+    if (bad != ~0ull) atomicMin(first_bad, bad);
+}
+void launch_finite_check(const float *pcm, int64_t n, unsigned long long *first_bad, hipStream_t s) {
+    if (n <= 0) return;
+    const unsigned g = (unsigned)std::min<int64_t>(4096, (n + 1023) / 1024);
+    hipLaunchKernelGGL(finite_check_kernel, dim3(g), dim3(256), 0, s, pcm, n, first_bad);
 }
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_frames == 0 || !(p.stages & 0x4u)) return;

@@ -32,6 +32,21 @@ def pack_events(clip_index, events):
     return rows
 
 
+def rows_from_packed(events, clip_ids):
+    """The structured event array of events_native.extract_batch(packed=True) (field `clip` = index into the batch)
+    -> the float64 [n, 10] rows of pack_events, with the batch indices replaced by the global clip ids."""
+    ev = np.asarray(events)
+    rows = np.zeros((len(ev), 10), np.float64)
+    if len(ev):
+        rows[:, 0] = np.asarray(clip_ids)[ev["clip"]]
+        for j, k in enumerate(("note", "start", "end", "velocity"), start=1):
+            rows[:, j] = ev[k]
+        rows[:, 5] = 1 - ev["track"].astype(np.int64)            # native: 1 main / 0 safe; rows: 0 main / 1 safe
+        rows[:, 6] = ev["technique"]
+        rows[:, 7], rows[:, 8], rows[:, 9] = ev["confidence"], ev["slope"], ev["rms_energy"]
+    return rows
+
+
 def unpack_events(rows):
     """Inverse of pack_events -> {clip_index: [event dict, ...]} (events keep their order)."""
     out = {}

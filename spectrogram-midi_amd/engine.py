@@ -13,7 +13,7 @@ import multiprocessing
 
 import numpy as np
 
-from . import _lib, audio_io, midi_logic, smf
+from . import _lib, audio_io, events_native, midi_logic, smf
 from .convert import note_to_hz
 
 _FMIN, _FMAX = note_to_hz("E2"), note_to_hz("C6")
@@ -41,6 +41,7 @@ class AegisEngine:
         self.verbose = verbose
         self.turbo_cores = None      # None -> multiprocessing.cpu_count(), as aegis_engine.py:187
         self._handle = None
+        self._freqs = None
 
     # ------------------------------------------------------------------ device context
     @property
@@ -111,20 +112,21 @@ class AegisEngine:
         res = self.analyze_arrays([y], turbo_mode=turbo_mode, rake_sensitivity=rake_sensitivity)
         return res[0]
 
-    def analyze_arrays(self, clips, turbo_mode=False, rake_sensitivity=0.6):
+    def analyze_arrays(self, clips, turbo_mode=False, rake_sensitivity=0.6, _concatenated=False):
         """Batch form: one ragged GPU batch for a folder of clips; element i is what
-        audio_to_midi returns for clip i (None for an empty clip)."""
+        audio_to_midi returns for clip i (None for an empty clip).  The arrays of a batch are slices of the batch's
+        buffers (one allocation per output, not one per clip)."""
         clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
         live = [i for i, c in enumerate(clips) if len(c) > 0]
-        for i in live:
-            _require_finite(clips[i])
         results = [None] * len(clips)
         if not live:
-            return results
+            return (results, None, None, live) if _concatenated else results
         self._say(f"[Aegis] Starting Perception Phase (Turbo: {turbo_mode})...")
         h = self.handle
+        # librosa.util.valid_audio (NaN / infinite samples raise) is tested on the device, where the samples are read anyway
+        bufs = off = None
         if turbo_mode:
-            frames = h.analyze_batch([clips[i] for i in live], rake_sensitivity=rake_sensitivity,
+            frames = h.analyze_batch([clips[i] for i in live], rake_sensitivity=rake_sensitivity, check_finite=True,
                                      stages=_lib.STAGE_MEL | _lib.STAGE_RAKE | _lib.STAGE_RMS, want_sdb=False)
             for i, r in zip(live, frames):
                 try:
@@ -135,15 +137,56 @@ class AegisEngine:
                     self._say(f"[Aegis] Parallel failed ({e}), falling back to stable core.")
                     p = h.analyze_batch([clips[i]], stages=_lib.STAGE_PYIN)[0]
                     r["f0"], r["voiced_flag"], r["voiced_prob"] = p["f0"], p["voiced_flag"], p["voiced_prob"]
+                r["f0"] = np.nan_to_num(r["f0"])
         else:
             self._say("[Aegis] Using Stable Single-core Analysis.")
-            frames = h.analyze_batch([clips[i] for i in live], rake_sensitivity=rake_sensitivity,
-                                     stages=_lib.STAGE_ALL, want_sdb=False)
+            frames, bufs, off = h.analyze_batch([clips[i] for i in live], rake_sensitivity=rake_sensitivity,
+                                                stages=_lib.STAGE_ALL, want_sdb=False, check_finite=True, f0_zero=True,
+                                                views=True, concatenated=True)
         for i, r in zip(live, frames):
-            results[i] = {"rake_mask": r["rake_mask"], "f0": np.nan_to_num(r["f0"]),
+            results[i] = {"rake_mask": r["rake_mask"], "f0": r["f0"],
                           "voiced_flag": r["voiced_flag"], "voiced_probs": r["voiced_prob"],
                           "rms": r["rms"], "y": clips[i]}
-        return results
+        return (results, bufs, off, live) if _concatenated else results
+
+    def audio_to_midi_batch(self, clips, want_midi=True, **kwargs):
+        """A folder of decoded clips -> (raw_data dicts, event lists, SMF bytes per clip): audio_to_midi + extract_events
+        for every clip (aegis_engine.py:41-181) as ONE analysis batch and ONE batched event extraction / MIDI rendering
+        (C++, clips in parallel).  Empty clips give (None, [], None).  kwargs as for both reference methods."""
+        turbo = kwargs.get("turbo_mode", False)
+        raws, bufs, off, live = self.analyze_arrays(clips, turbo_mode=turbo, rake_sensitivity=kwargs.get("rake_sensitivity", 0.6),
+                                                    _concatenated=True)
+        events, blobs = [[] for _ in clips], [None] * len(clips)
+        if not live:
+            return raws, events, blobs
+        passthrough = {k: v for k, v in kwargs.items() if k not in _ENGINE_ONLY_KWARGS + ("midi_program",)}
+        smf_kw = dict(midi_program=kwargs.get("midi_program", 27), vibrato_rate=kwargs.get("vibrato_rate", 5.0),
+                      vibrato_depth=kwargs.get("vibrato_depth", 0.3))
+        if bufs is None:         # Turbo Mode: per-clip arrays of different lengths (SURVEY Q4), truncated as extract_events does
+            cat = {k: [] for k in ("rake_mask", "f0", "voiced_flag", "voiced_probs", "rms")}
+            lens = []
+            for i in live:
+                r = raws[i]
+                n = min(len(r["rake_mask"]), len(r["f0"]), len(r["rms"]))
+                lens.append(n)
+                for k in cat:
+                    cat[k].append(r[k][:n])
+            off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+            bufs = {("voiced_prob" if k == "voiced_probs" else k): np.concatenate(v) for k, v in cat.items()}
+        grid = {}
+        if "pitch_bin" in bufs:       # the analysis's own bins: hz_to_midi from a 441-entry table
+            if self._freqs is None:
+                self._freqs = self.handle.table("freqs")
+            grid = dict(pitch_bin=bufs["pitch_bin"], freqs=self._freqs)
+        res = events_native.extract_batch(off, bufs["rake_mask"], bufs["f0"], bufs["voiced_flag"], bufs["voiced_prob"], bufs["rms"],
+                                          self.sr, self.hop_length, kwargs.get("confidence_threshold", 0.70),
+                                          want_midi=want_midi, **grid, **smf_kw, **passthrough)
+        per, bl = res if want_midi else (res, None)
+        for j, i in enumerate(live):
+            events[i] = per[j]
+            if want_midi:
+                blobs[i] = bl[j]
+        return raws, events, blobs
 
     def extract_events(self, raw_data, output_mid, **kwargs):
         """Logic filter layer (aegis_engine.py:77-181): raw_data -> events, optional SMF to a
@@ -151,20 +194,21 @@ class AegisEngine:
         keys = ("rake_mask", "f0", "voiced_flag", "voiced_probs", "rms")
         n = min(len(raw_data["rake_mask"]), len(raw_data["f0"]), len(raw_data["rms"]))
         rake_mask, f0, voiced_flag, voiced_probs, rms = (raw_data[k][:n] for k in keys)
-        passthrough = {k: v for k, v in kwargs.items() if k not in _ENGINE_ONLY_KWARGS}
-        events = midi_logic.get_midi_events(
-            rake_mask=rake_mask, f0=f0, voiced_flag=voiced_flag, active_probs=voiced_probs, rms=rms,
-            sr=self.sr, hop_length=self.hop_length,
-            confidence_threshold=kwargs.get("confidence_threshold", 0.70), **passthrough)
+        passthrough = {k: v for k, v in kwargs.items() if k not in _ENGINE_ONLY_KWARGS + ("midi_program",)}
+        smf_kw = dict(midi_program=kwargs.get("midi_program", 27), vibrato_rate=kwargs.get("vibrato_rate", 5.0),
+                      vibrato_depth=kwargs.get("vibrato_depth", 0.3))
+        res = events_native.extract_batch([0, n], rake_mask, f0, voiced_flag, voiced_probs, rms, self.sr, self.hop_length,
+                                          kwargs.get("confidence_threshold", 0.70), want_midi=bool(output_mid), **smf_kw,
+                                          **passthrough)
         if output_mid:
-            blob = smf.render(events, self.sr, self.hop_length, midi_program=kwargs.get("midi_program", 27),
-                              vibrato_rate=kwargs.get("vibrato_rate", 5.0),
-                              vibrato_depth=kwargs.get("vibrato_depth", 0.3))
+            events, blob = res[0][0], res[1][0]
             if hasattr(output_mid, "write"):
                 output_mid.write(blob)
             else:
                 with open(output_mid, "wb") as f:
                     f.write(blob)
+        else:
+            events = res[0]
         return events
 
     # ------------------------------------------------------------------ Turbo Mode

@@ -68,7 +68,7 @@ def test_bare_gpus_2_runs_two_ranks_and_gathers_events():
     assert abs(sum(line["rank_audio_seconds"]) - 2 * 3 * 8) < 0.1
     # sub-records of the same run: the host-buffer entry and the engine surface, whole-job rates
     assert line["host_inclusive"]["value"] > 0 and line["engine_e2e"]["value"] > 0 and line["engine_e2e"]["midi_bytes"] > 0
-    assert line["engine_e2e"]["audio_to_midi_ms"] >= line["engine_e2e"]["analyze_ms"] and line["uniform_shard"] is None
+    assert line["engine_e2e"]["per_clip_api"]["audio_to_midi_ms"] >= line["engine_e2e"]["per_clip_api"]["analyze_ms"] and line["uniform_shard"] is None
 
 
 @pytest.mark.gpu

@@ -70,6 +70,34 @@ def test_sweep_and_empty(eng):
         eng.analyze_array(np.array([0.0, np.nan, 0.1], np.float32))
 
 
+def test_audio_to_midi_batch_equals_the_per_clip_calls(eng, test_clips):
+    """AegisEngine.audio_to_midi_batch: one GPU batch + one batched (C++) event extraction / SMF rendering == the
+    reference's two calls per clip, dict for dict and byte for byte; non-finite audio is refused (on the device)."""
+    clips = [test_clips[k] for k in ("guitar", "sweep", "empty", "tiny", "notes", "silence")]
+    for kw in ({}, {"min_note_duration_ms": 100, "sustain_ms": 200, "midi_program": 30, "confidence_threshold": 0.3}):
+        raws, evs, blobs = eng.audio_to_midi_batch(clips, **kw)
+        assert len(raws) == len(evs) == len(blobs) == len(clips)
+        for y, raw, ev, blob in zip(clips, raws, evs, blobs):
+            if len(y) == 0:
+                assert raw is None and ev == [] and blob is None
+                continue
+            ref = oengine.audio_to_midi(y)
+            assert_raw_equal(raw, ref)
+            ev_ref, blob_ref = oengine.extract_events(ref, want_smf=True, **kw)
+            assert_events_equal(ev, ev_ref)
+            assert blob == blob_ref
+            buf = io.BytesIO()
+            assert_events_equal(eng.extract_events(raw, buf, **kw), ev_ref)
+            assert buf.getvalue() == blob_ref
+    bad = test_clips["notes"].copy()
+    bad[12345] = np.inf
+    with pytest.raises(ValueError, match="not finite everywhere .clip 1, sample 12345"):
+        eng.audio_to_midi_batch([test_clips["tiny"], bad])
+    r, e, b = eng.audio_to_midi_batch([test_clips["notes"]], want_midi=False, turbo_mode=True)
+    ref = oengine.audio_to_midi(test_clips["notes"], turbo_mode=True, num_cores=eng.turbo_cores or os.cpu_count())
+    assert_events_equal(e[0], oengine.extract_events(ref)) and b[0] is None
+
+
 def test_turbo_mode_matches_reference_chunking(eng):
     y = signals.guitar_clip(12.0, seed=3)
     for cores in (8, 3):

@@ -18,7 +18,12 @@ for _ in range(3):
     t3 = time.perf_counter()
     ta.append(t1 - t0); te.append(t2 - t1); tm.append(t3 - t2)
 a, e, m = (float(np.median(x)) for x in (ta, te, tm))
+tb = []
+for _ in range(3):
+    t0 = time.perf_counter(); eng.audio_to_midi_batch(clips); tb.append(time.perf_counter() - t0)
+b = float(np.median(tb))
 print(json.dumps({"workload": "64 x 180 s through AegisEngine (host arrays in, dicts / events / SMF bytes out)",
+                  "audio_to_midi_batch_s": round(b, 4), "audio_s_per_s_batch_to_midi": round(64 * 180 / b, 1),
                   "analyze_arrays_s": round(a, 4), "extract_events_s": round(e, 4), "extract_events_with_smf_s": round(m, 4),
                   "events_per_clip": int(np.mean([len(x) for x in evs])),
                   "audio_s_per_s_analyze": round(64 * 180 / a, 1), "audio_s_per_s_to_midi": round(64 * 180 / (a + m), 1)}))
