@@ -83,6 +83,9 @@ typedef struct aegis_outputs {
     float *S_dB;          /* per clip [n_mels, F_clip] C-order, clip after clip (n_mels*F_total) */
     int16_t *pitch_bin;   /* [F_total]  the decoded pitch bin (f0 == freqs[bin], aegis_get_table "freqs"), -1 where unvoiced:
                              lets the event logic take hz_to_midi(f0) from a table of n_pitch_bins entries */
+    float *sdb_col_means; /* [3][F_total]  per frame np.mean(S_dB, axis=0), np.mean(S_dB[:n_mels/2], axis=0) and
+                             np.mean(S_dB[n_mels/2:], axis=0) in NumPy's order (float32, row after row): all the v2 guitar
+                             filters read of the dB image (guitar_specific.py:60-141), without moving the image */
 } aegis_outputs;
 
 int aegis_abi_version(void);
@@ -162,11 +165,19 @@ void aegis_stream_free(aegis_stream *st);
  *  AEGIS_TREND_ARTICULATION  window, sensitivity            int8 codes   .detect_articulation_bollinger (:148-197): 0 None 1 normal 2 bend 3 vibrato 4 noise
  *  AEGIS_TREND_MACD          fast, slow, signal             macd,signal,hist .macd (:203-226)
  *  AEGIS_TREND_SLIDES        threshold                      int8 codes   .detect_slides_macd (:228-268): 0 None 1 normal 2 slide_up 3 slide_down
- *  AEGIS_TREND_RSI           period                         out          .rsi (:274-320)
+ *  AEGIS_TREND_RSI           period [, averages]            out          .rsi (:274-320); averages != 0: the two Wilder averages
+ *                                                          (avg_gain, avg_loss; NaN where the RSI is the constant 50) instead, for callers
+ *                                                          that need the RSI at a few positions only (filter_ghost_notes_rsi :322-362)
  *  AEGIS_TREND_SAVGOL        window, symmetric, coef[window] out         FinancialNoiseFilters.savitzky_golay (financial_filters.py:25-59); coef = reversed scipy savgol_coeffs
  *  AEGIS_TREND_KALMAN        process_var, measurement_var   out          .kalman_filter (:62-99)
  *  AEGIS_TREND_HOLT          alpha, beta                    out          .holt_winters (:102-141)
  *  AEGIS_TREND_CONSENSUS     k  (x = k stacked rows, n_series = 1)  median, confidence   multi_filter_consensus (:256-298)
+ *  AEGIS_TREND_PITCH_ANALYSIS  sg_window, sg_symmetric, sg_coef[sg_window], kalman q, r, holt alpha, beta, band window, band num_std,
+ *                            slide threshold       trend, int8 articulation codes, int8 slide codes, confidence
+ *                            FinancialPitchAnalyzer.analyze_pitch_financial (financial_analysis.py:368-423) as ONE call: the
+ *                            Savitzky-Golay / Kalman / Holt consensus, the Bollinger articulation and MACD slide state machines and
+ *                            the band-width confidence -- the ops above, with the four independent sequential walks (Kalman, Holt,
+ *                            NaN compaction, MACD) on four streams at once, one upload and one synchronisation
  *
  * A series shorter than the window is AEGIS_ERR_INVALID for SMA/Bollinger (the reference raises IndexError). */
 #define AEGIS_TREND_SMA 1
@@ -180,6 +191,7 @@ void aegis_stream_free(aegis_stream *st);
 #define AEGIS_TREND_KALMAN 9
 #define AEGIS_TREND_HOLT 10
 #define AEGIS_TREND_CONSENSUS 11
+#define AEGIS_TREND_PITCH_ANALYSIS 12
 int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
                 const double *params, int32_t n_params, void *const *outs, int32_t n_outs);
 

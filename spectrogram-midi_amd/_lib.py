@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("AEGIS_HIP_LIB", os.path.join(_HERE, "libaegis_hip.so"
 STAGE_MEL, STAGE_RAKE, STAGE_PYIN, STAGE_RMS, STAGE_ALL = 0x1, 0x2, 0x4, 0x8, 0xF
 OPT_CHECK_FINITE, OPT_F0_ZERO = 0x10, 0x20
 (TREND_SMA, TREND_EMA, TREND_BOLLINGER, TREND_ARTICULATION, TREND_MACD, TREND_SLIDES, TREND_RSI, TREND_SAVGOL,
- TREND_KALMAN, TREND_HOLT, TREND_CONSENSUS) = range(1, 12)
+ TREND_KALMAN, TREND_HOLT, TREND_CONSENSUS, TREND_PITCH_ANALYSIS) = range(1, 13)
 OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95
 PYIN_INIT_UNVOICED, PYIN_INIT_UNIFORM = 0, 1      # aegis_config.pyin_init
 _PYIN_INIT = {"unvoiced": 0, "uniform": 1, 0: 0, 1: 1}
@@ -35,7 +35,7 @@ class StreamFrames(C.Structure):
 
 class Outputs(C.Structure):
     _fields_ = [("f0", C.c_void_p), ("voiced_flag", C.c_void_p), ("voiced_prob", C.c_void_p),
-                ("rms", C.c_void_p), ("rake_mask", C.c_void_p), ("S_dB", C.c_void_p), ("pitch_bin", C.c_void_p)]
+                ("rms", C.c_void_p), ("rake_mask", C.c_void_p), ("S_dB", C.c_void_p), ("pitch_bin", C.c_void_p), ("sdb_col_means", C.c_void_p)]
 
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
@@ -212,7 +212,7 @@ class Handle:
         return {"wave_steps": int(v[0]), "list_only": int(v[1]), "skipped": int(v[2])}
 
     def analyze_batch(self, clips, rake_sensitivity=0.6, stages=STAGE_ALL, want_sdb=True, check_finite=False,
-                      f0_zero=False, views=False, concatenated=False):
+                      f0_zero=False, views=False, concatenated=False, want_col_means=False):
         """clips: list of float32 1-D arrays (host).  Returns a list of per-clip dicts with the
         dtypes of the reference's raw_data (aegis_engine.py:72-75); f0 keeps NaN where unvoiced unless f0_zero
         (np.nan_to_num, aegis_engine.py:69).  check_finite: librosa's valid_audio test on the device -> ValueError.
@@ -242,6 +242,8 @@ class Handle:
             bufs["rake_mask"] = np.empty(F, np.uint8)
         if (stages & STAGE_MEL) and want_sdb:
             bufs["S_dB"] = np.empty(F * self.n_mels, np.float32)
+        if (stages & STAGE_MEL) and want_col_means:
+            bufs["sdb_col_means"] = np.empty(3 * F, np.float32)     # batch-level only: [3][F] all / low half / high half
         for k, v in bufs.items():
             setattr(out, k, v.ctypes.data)
         flags = int(stages) | (OPT_CHECK_FINITE if check_finite else 0) | (OPT_F0_ZERO if f0_zero else 0)
@@ -258,7 +260,7 @@ class Handle:
         for Fc in frames:
             d = {}
             for k, v in bufs.items():
-                if k == "pitch_bin":
+                if k in ("pitch_bin", "sdb_col_means"):
                     continue
                 if k == "S_dB":
                     a = v[fo * self.n_mels:(fo + Fc) * self.n_mels].reshape(self.n_mels, Fc)
@@ -292,7 +294,8 @@ class Handle:
         off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
         total = int(off[-1])
         par = np.ascontiguousarray(params, dtype=np.float64)
-        outs = [np.empty(total, dtype=out_dtype) for _ in range(n_out)]
+        dtypes = out_dtype if isinstance(out_dtype, (list, tuple)) else [out_dtype] * n_out
+        outs = [np.empty(total, dtype=dt) for dt in dtypes]
         ptrs = (C.c_void_p * n_out)(*[o.ctypes.data for o in outs])
         self._check(self.lib.aegis_trend(self._h, int(op), flat.ctypes.data, off.ctypes.data, len(lens),
                                          par.ctypes.data, len(par), ptrs, n_out))

@@ -82,7 +82,8 @@ struct aegis_handle {
     CqtBank cqt_bank;
     DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
-    DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb, io_bin;
+    DevBuf t_pa;                              // scratch of the fused pitch analysis: 12 rows of doubles + 1 of bytes
+    DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb, io_bin, io_colmean;
     int32_t lag_stride = 0, yin_stride = 0, obs_stride = 0;
     std::vector<PassMeta> metas;
     // last pass geometry for aegis_debug_fetch
@@ -358,8 +359,8 @@ static void destroy_now(aegis_handle *h) noexcept {
                           &w.vstate, &w.chunk_lo, &w.chunk_flag})
             free_buf(*b);
     for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->finite_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
-                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
-                      &h->io_sdb, &h->io_bin})
+                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->t_pa, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
+                      &h->io_sdb, &h->io_bin, &h->io_colmean})
         free_buf(*b);
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
@@ -742,6 +743,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.out_rms = (stages & AEGIS_STAGE_RMS) ? dout->rms : nullptr;
         p.out_rake = (stages & AEGIS_STAGE_RAKE) ? dout->rake_mask : nullptr;
         p.out_sdb = (stages & AEGIS_STAGE_MEL) ? dout->S_dB : nullptr;
+        p.out_colmean = (stages & AEGIS_STAGE_MEL) ? dout->sdb_col_means : nullptr;
+        p.out_total = total_frames;
         p.rake_ratio = rake_sensitivity;
         p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
         if (opts & AEGIS_OPT_F0_ZERO) p.f0_unvoiced = 0.0;
@@ -877,6 +880,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     const int nm = h->tab.n_mels;
     if ((stages & AEGIS_STAGE_PYIN) && out->f0) { if ((rc = ensure(h, h->io_f0, F * 8))) return rc; d.f0 = static_cast<double *>(h->io_f0.p); }
     if ((stages & AEGIS_STAGE_PYIN) && out->voiced_flag) { if ((rc = ensure(h, h->io_voiced, F))) return rc; d.voiced_flag = static_cast<uint8_t *>(h->io_voiced.p); }
+    if ((stages & AEGIS_STAGE_MEL) && out->sdb_col_means) { if ((rc = ensure(h, h->io_colmean, F * 12))) return rc; d.sdb_col_means = static_cast<float *>(h->io_colmean.p); }
     if ((stages & AEGIS_STAGE_PYIN) && out->pitch_bin) { if ((rc = ensure(h, h->io_bin, F * 2))) return rc; d.pitch_bin = static_cast<int16_t *>(h->io_bin.p); }
     if ((stages & AEGIS_STAGE_PYIN) && out->voiced_prob) { if ((rc = ensure(h, h->io_vprob, F * 8))) return rc; d.voiced_prob = static_cast<double *>(h->io_vprob.p); }
     if ((stages & AEGIS_STAGE_RMS) && out->rms) { if ((rc = ensure(h, h->io_rms, F * 4))) return rc; d.rms = static_cast<float *>(h->io_rms.p); }
@@ -887,6 +891,7 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if (rc != AEGIS_OK) return rc;
     if (d.f0) HIPCHK(h, hipMemcpyAsync(out->f0, d.f0, F * 8, hipMemcpyDeviceToHost, s));
     if (d.voiced_flag) HIPCHK(h, hipMemcpyAsync(out->voiced_flag, d.voiced_flag, F, hipMemcpyDeviceToHost, s));
+    if (d.sdb_col_means) HIPCHK(h, hipMemcpyAsync(out->sdb_col_means, d.sdb_col_means, F * 12, hipMemcpyDeviceToHost, s));
     if (d.pitch_bin) HIPCHK(h, hipMemcpyAsync(out->pitch_bin, d.pitch_bin, F * 2, hipMemcpyDeviceToHost, s));
     if (d.voiced_prob) HIPCHK(h, hipMemcpyAsync(out->voiced_prob, d.voiced_prob, F * 8, hipMemcpyDeviceToHost, s));
     if (d.rms) HIPCHK(h, hipMemcpyAsync(out->rms, d.rms, F * 4, hipMemcpyDeviceToHost, s));
@@ -1295,7 +1300,7 @@ int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *off
         if (offsets[i + 1] < offsets[i]) { h->err = "offsets must be non-decreasing"; return AEGIS_ERR_INVALID; }
 #define ENS(buf, bytes) if ((rc = ensure(h, h->buf, (size_t)(bytes))) != AEGIS_OK) return rc
     ENS(t_x, n_in * 8); ENS(t_off, (n_series + 1) * 8);
-    ENS(t_a, total * 8); ENS(t_b, total * 8); ENS(t_c, total * 8); ENS(t_d, total * 8); ENS(t_e, total * 8);
+    ENS(t_a, total * 8); ENS(t_b, total * 8); ENS(t_c, total * 8); ENS(t_d, total * 8); ENS(t_e, std::max<int64_t>(total, 256) * 8);
     ENS(t_i8, total); ENS(t_i64a, total * 8); ENS(t_i64b, (n_series + 1) * 8);
 #undef ENS
     HIPCHK(h, hipMemcpyAsync(h->t_x.p, x, n_in * 8, hipMemcpyHostToDevice, s));
@@ -1355,6 +1360,12 @@ int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *off
         if (!need(1, 1)) return AEGIS_ERR_INVALID;
         const int per = (int)params[0];
         if (per < 1 || per > 128) { h->err = "rsi period must be 1..128"; return AEGIS_ERR_INVALID; }
+        if (n_params >= 2 && params[1] != 0.0) {          // the two Wilder averages instead of the RSI (see trend.hip)
+            if (!need(2, 2)) return AEGIS_ERR_INVALID;
+            trend_rsi_averages(a, per, A, B, s);
+            HIPCHK(h, back(outs[0], A, total * 8)); HIPCHK(h, back(outs[1], B, total * 8));
+            break;
+        }
         trend_rsi(a, per, A, s);
         HIPCHK(h, back(outs[0], A, total * 8));
         break;
@@ -1383,6 +1394,49 @@ int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *off
     case AEGIS_TREND_CONSENSUS: {
         trend_consensus(a.x, (int)params[0], total, A, B, s);
         HIPCHK(h, back(outs[0], A, total * 8)); HIPCHK(h, back(outs[1], B, total * 8));
+        break;
+    }
+    case AEGIS_TREND_PITCH_ANALYSIS: {
+        // analyze_pitch_financial (financial_analysis.py:368-423): the same kernels as the single ops above, the four
+        // independent sequential walks on four streams at once
+        if (n_params < 2 || !need(2 + (int)params[0] + 7, 4)) { h->err = "pitch analysis params: sg window, symmetric, coefficients, q, r, alpha, beta, band window, num_std, slide threshold"; return AEGIS_ERR_INVALID; }
+        const int w = (int)params[0];
+        if (w < 1 || (w & 1) == 0 || w > 255) { h->err = "savgol window must be odd, 1..255"; return AEGIS_ERR_INVALID; }
+        const double *pp = params + 2 + w;
+        const int bw = (int)pp[4];
+        if (bw < 1 || bw > 128 || min_len() < bw) { h->err = "band window must be 1..128 and not longer than any series"; return AEGIS_ERR_INVALID; }
+        if ((rc = ensure(h, h->t_pa, (size_t)total * (12 * 8 + 1) + 256)) != AEGIS_OK) return rc;
+        double *R = static_cast<double *>(h->t_pa.p);
+        double *stack = R;                              // [3][total]: savgol, kalman, holt (the order multi_filter_consensus stacks them)
+        double *ma = R + 3 * total, *up = R + 4 * total, *lo = R + 5 * total, *semi = R + 6 * total;
+        double *mm = R + 7 * total, *sg = R + 8 * total, *hh = R + 9 * total, *cx = R + 10 * total, *conf = R + 11 * total;
+        int8_t *slide_codes = reinterpret_cast<int8_t *>(R + 12 * total);
+        hipStream_t q1 = h->stream2, q2 = h->stream3, q3 = h->stream4;
+        while (h->sync_events.size() < 5) { hipEvent_t e; HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming)); h->sync_events.push_back(e); }
+        HIPCHK(h, hipMemcpyAsync(E, params + 2, (size_t)w * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipEventRecord(h->sync_events[0], s));          // input, offsets and coefficients are on the device
+        for (hipStream_t q : {q1, q2, q3}) HIPCHK(h, hipStreamWaitEvent(q, h->sync_events[0], 0));
+        // s: MACD of the semitone track -> slide codes
+        trend_semitones(a.x, total, semi, s);
+        { TrendArgs st{semi, a.off, n_series, total}; trend_macd(st, 5, 20, 9, mm, sg, hh, s); }
+        trend_slides(mm, hh, total, pp[6], slide_codes, s);
+        // q1: Kalman, then the bands and the articulation state machine
+        trend_kalman(a, pp[0], pp[1], stack + total, q1);
+        trend_bollinger(a, bw, pp[5], ma, up, lo, q1);
+        trend_articulation(a, up, lo, I8, q1);
+        trend_band_confidence(a.x, up, lo, total, conf, q1);
+        // q2: Holt; q3: NaN compaction + Savitzky-Golay
+        trend_holt(a, pp[2], pp[3], stack + 2 * total, q2);
+        trend_savgol(a, E, w, (int)params[1], cx, static_cast<int64_t *>(h->t_i64a.p), static_cast<int64_t *>(h->t_i64b.p), stack, q3);
+        int ei = 1;
+        for (hipStream_t q : {q1, q2, q3}) {
+            HIPCHK(h, hipEventRecord(h->sync_events[ei], q));
+            HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[ei], 0));
+            ++ei;
+        }
+        trend_consensus(stack, 3, total, A, B, s);
+        HIPCHK(h, back(outs[0], A, total * 8)); HIPCHK(h, back(outs[1], I8, total));
+        HIPCHK(h, back(outs[2], slide_codes, total)); HIPCHK(h, back(outs[3], conf, total * 8));
         break;
     }
     default:

@@ -96,6 +96,7 @@ struct PassParams {
     double *out_f0; uint8_t *out_voiced; double *out_vprob; float *out_rms;
     uint8_t *out_rake; float *out_sdb;   // clip c's dB image starts at n_mels * out_off[c]
     int16_t *out_bin;                    // decoded pitch bin, -1 unvoiced
+    float *out_colmean; int64_t out_total;   // [3][out_total] column means of the dB image (all / low half / high half of the mel rows)
     double rake_ratio;
     int32_t rake_min_frames, rake_max_frames;
     double f0_unvoiced;                  // what an unvoiced frame's f0 reads: NaN (librosa.pyin fill_na) or 0.0 (np.nan_to_num)

@@ -980,6 +980,22 @@ __global__ __launch_bounds__(256) void db_rake_kernel(PassParams p) {
         }
     }
     __syncthreads();
+    if (p.out_colmean != nullptr && tid < 64 && rclip[tid] >= 0) {
+        // np.mean(S_dB, axis=0) and the two half-image means of guitar_specific.py:60-141: float32 sums row after row
+        // (NumPy reduces a C-ordered [n_mels, F] array over axis 0 one row at a time), divided by the row count
+        const int c = rclip[tid], mid = nm / 2;
+        const float *row = tile[tid];
+        float a = row[0];
+        for (int m = 1; m < mid; ++m) a = a + row[m];
+        const float lo_sum = a;
+        float hs = row[mid];
+        for (int m = mid + 1; m < nm; ++m) hs = hs + row[m];
+        for (int m = mid; m < nm; ++m) a = a + row[m];
+        const int64_t fo = out_index(p, c, fb + tid - p.frame_off[c]);
+        p.out_colmean[fo] = a / (float)nm;
+        p.out_colmean[p.out_total + fo] = lo_sum / (float)mid;
+        p.out_colmean[2 * p.out_total + fo] = hs / (float)(nm - mid);
+    }
     if (p.out_sdb != nullptr) {
         for (int idx = tid; idx < 64 * nm; idx += 256) {
             const int m = idx >> 6, r = idx & 63;

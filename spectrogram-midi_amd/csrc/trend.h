@@ -21,10 +21,12 @@ void trend_macd(const TrendArgs &a, int fast, int slow, int sig, double *m, doub
 void trend_semitones(const double *x, int64_t total, double *out, hipStream_t s);
 void trend_slides(const double *macd, const double *hist, int64_t total, double thr, int8_t *codes, hipStream_t s);
 void trend_rsi(const TrendArgs &a, int period, double *out, hipStream_t s);
+void trend_rsi_averages(const TrendArgs &a, int period, double *avg_gain, double *avg_loss, hipStream_t s);
 void trend_savgol(const TrendArgs &a, const double *coef_rev, int window, int symmetric, double *cx, int64_t *cpos,
                   int64_t *ccount, double *out, hipStream_t s);
 void trend_kalman(const TrendArgs &a, double q, double r, double *out, hipStream_t s);
 void trend_holt(const TrendArgs &a, double alpha, double beta, double *out, hipStream_t s);
+void trend_band_confidence(const double *x, const double *upper, const double *lower, int64_t total, double *out, hipStream_t s);
 void trend_consensus(const double *stacked, int k, int64_t len, double *med, double *conf, hipStream_t s);
 
 }  // namespace aegis

@@ -268,18 +268,25 @@ __global__ void slides_kernel(const double *__restrict__ macd, const double *__r
 }
 
 // ---- rsi (financial_analysis.py:274-320), Wilder smoothing, one lane per series ---------------
+// AVERAGES: write the two Wilder averages (avg_gain to `out`, avg_loss to `out2`; NaN where the RSI is the constant 50)
+// instead of the RSI: the ghost-note filter reads the RSI at a hundred positions of a 77 k-element track, and the two
+// divisions that turn the averages into an RSI value are then done for those positions only (by the caller, the same
+// IEEE operations) instead of for every element on the one lane that walks the series.
+template <bool AVERAGES>
 __global__ __launch_bounds__(64) void rsi_kernel(const double *__restrict__ x, const int64_t *__restrict__ off, int n_series, int period,
-                           double *__restrict__ out) {
+                           double *__restrict__ out, double *__restrict__ out2) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_series) return;
     const double *d = x + off[s];
     double *o = out + off[s];
+    double *o2 = AVERAGES ? out2 + off[s] : nullptr;
     const int64_t n = off[s + 1] - off[s];
+    const double flat = AVERAGES ? (double)NAN : 50.0;
     if (n - 1 < period || period < 1) {
-        for (int64_t i = 0; i < n; ++i) o[i] = 50.0;
+        for (int64_t i = 0; i < n; ++i) { o[i] = flat; if (AVERAGES) o2[i] = flat; }
         return;
     }
-    for (int64_t i = 0; i < period; ++i) o[i] = 50.0;       // the rest is written by the recurrence below
+    for (int64_t i = 0; i < period; ++i) { o[i] = flat; if (AVERAGES) o2[i] = flat; }       // the rest is written by the recurrence below
     auto gain = [&](int64_t i) { const double dl = d[i + 1] - d[i]; return dl > 0 ? dl : 0.0; };
     auto loss = [&](int64_t i) { const double dl = d[i + 1] - d[i]; return dl < 0 ? -dl : 0.0; };
     double ag, al;
@@ -299,12 +306,14 @@ __global__ __launch_bounds__(64) void rsi_kernel(const double *__restrict__ x, c
     auto step = [&](double dl, int64_t i) {
         ag = (ag * pm1 + (dl > 0 ? dl : 0.0)) / pd;
         al = (al * pm1 + (dl < 0 ? -dl : 0.0)) / pd;
+        if (AVERAGES) { o[i] = ag; o2[i] = al; return; }
         const double rs = ag / al;
         const double val = 100 - (100 / (1 + rs));
         o[i] = al == 0 ? 100.0 : val;
     };
     {   // i = period: the seed averages themselves
-        if (al == 0) o[period] = 100;
+        if (AVERAGES) { o[period] = ag; o2[period] = al; }
+        else if (al == 0) o[period] = 100;
         else { const double rs = ag / al; o[period] = 100 - (100 / (1 + rs)); }
     }
     int64_t i = (int64_t)period + 1;                // element i uses d[i] - d[i-1]
@@ -459,6 +468,18 @@ __global__ void consensus_kernel(const double *__restrict__ stacked, int k, int6
     med[i] = (cnt & 1) ? v[cnt / 2] : (v[cnt / 2 - 1] == v[cnt / 2] ? v[cnt / 2] : (v[cnt / 2 - 1] + v[cnt / 2]) / 2.0);
 }
 
+// analyze_pitch_financial's confidence (financial_analysis.py:409-417): 1 / (1 + band width) where the sample and the
+// width are numbers (1 when the width is not positive), 0 elsewhere
+__global__ void band_confidence_kernel(const double *__restrict__ x, const double *__restrict__ upper, const double *__restrict__ lower,
+                                       int64_t total, double *__restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const double v = x[i], w = upper[i] - lower[i];
+    double c = 0.0;
+    if (v == v && w == w) c = w > 0 ? 1.0 / (1.0 + w) : 1.0;
+    out[i] = c;
+}
+
 // ------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------
@@ -488,7 +509,10 @@ void trend_slides(const double *macd, const double *hist, int64_t total, double 
     if (total) hipLaunchKernelGGL(slides_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, macd, hist, total, thr, codes);
 }
 void trend_rsi(const TrendArgs &a, int period, double *out, hipStream_t s) {
-    if (a.n_series) hipLaunchKernelGGL(rsi_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, period, out);
+    if (a.n_series) hipLaunchKernelGGL(rsi_kernel<false>, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, period, out, (double *)nullptr);
+}
+void trend_rsi_averages(const TrendArgs &a, int period, double *avg_gain, double *avg_loss, hipStream_t s) {
+    if (a.n_series) hipLaunchKernelGGL(rsi_kernel<true>, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, period, avg_gain, avg_loss);
 }
 void trend_savgol(const TrendArgs &a, const double *coef_rev, int window, int symmetric, double *cx, int64_t *cpos,
                   int64_t *ccount, double *out, hipStream_t s) {
@@ -503,6 +527,9 @@ void trend_kalman(const TrendArgs &a, double q, double r, double *out, hipStream
 }
 void trend_holt(const TrendArgs &a, double alpha, double beta, double *out, hipStream_t s) {
     if (a.n_series) hipLaunchKernelGGL(holt_kernel, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, alpha, beta, out);
+}
+void trend_band_confidence(const double *x, const double *upper, const double *lower, int64_t total, double *out, hipStream_t s) {
+    if (total) hipLaunchKernelGGL(band_confidence_kernel, dim3(blocks(total, 256)), dim3(256), 0, s, x, upper, lower, total, out);
 }
 void trend_consensus(const double *stacked, int k, int64_t len, double *med, double *conf, hipStream_t s) {
     if (len) hipLaunchKernelGGL(consensus_kernel, dim3(blocks(len, 256)), dim3(256), 0, s, stacked, k, len, med, conf);

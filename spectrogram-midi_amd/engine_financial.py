@@ -7,8 +7,8 @@ import numpy as np
 
 from . import _lib, audio_io
 from .convert import note_to_hz
-from .guitar import apply_guitar_filters
-from .midi_logic_financial import get_midi_events_financial
+from .guitar import apply_guitar_filters, apply_guitar_filters_from_means
+from .midi_logic_financial import get_midi_events_financial, get_midi_events_financial_batch
 from .smf import Track
 
 
@@ -58,6 +58,36 @@ class AegisFinancialEngine:
             rake_mask=rake, f0=f0, voiced_flag=voiced, active_probs=r["voiced_prob"], rms=r["rms"], sr=self.sr,
             hop_length=self.hop_length, confidence_threshold=kwargs.get("confidence_threshold", None),
             use_financial=kwargs.get("use_financial", True), verbose=self.verbose, **passthrough)
+
+    def analyze_arrays(self, clips, **kwargs):
+        """analyze_array for a folder of decoded clips: ONE ragged GPU analysis batch (the guitar filters read the three
+        column means of the dB image the library computes beside it, so the image itself never leaves the GPU), ONE fused
+        pitch-analysis call and ONE ghost-note RSI call for all clips (midi_logic_financial.get_midi_events_financial_batch).
+        Element i is what analyze_array(clips[i], **kwargs) returns."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        if not clips:
+            return []
+        use_guitar = kwargs.get("use_guitar_filters", True)
+        res, bufs, off = self.handle.analyze_batch(clips, rake_sensitivity=kwargs.get("rake_sensitivity", 0.6), want_sdb=False,
+                                                   want_col_means=use_guitar, views=True, concatenated=True)
+        F = int(off[-1])
+        items = []
+        for i, r in enumerate(res):
+            f0, voiced, rake = r["f0"], r["voiced_flag"], r["rake_mask"]
+            if use_guitar:
+                a, b = int(off[i]), int(off[i + 1])
+                cm = bufs["sdb_col_means"]
+                g = apply_guitar_filters_from_means(f0, voiced, (cm[a:b], cm[F + a:F + b], cm[2 * F + a:2 * F + b]),
+                                                    self.hop_length, self.sr, rake)
+                f0, rake = g["f0"], g["rake_mask"]
+                voiced = g["voiced"] & ~g["mute_mask"]
+            items.append({"rake_mask": rake, "f0": f0, "voiced_flag": voiced, "active_probs": r["voiced_prob"], "rms": r["rms"]})
+        passthrough = {k: v for k, v in kwargs.items()
+                       if k not in ("confidence_threshold", "rake_sensitivity", "use_financial")}
+        return get_midi_events_financial_batch(items, self.sr, self.hop_length,
+                                               confidence_threshold=kwargs.get("confidence_threshold", None),
+                                               use_financial=kwargs.get("use_financial", True), verbose=self.verbose,
+                                               **passthrough)
 
     def render_midi(self, events):
         """aegis_engine_financial.py:190-245: track_name metas, note_on at the start tick, note_off after

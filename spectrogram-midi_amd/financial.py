@@ -109,18 +109,18 @@ class FinancialPitchAnalyzer:
     def rsi(self, data, period=14):
         return self._op(_lib.TREND_RSI, data, [period])[0]
 
-    def filter_ghost_notes_rsi(self, note_events, rsi_threshold=70):
-        """financial_analysis.py:322-362, including its mixed units: `start`/`end` are scaled by 10 as if
-        they were seconds whatever the caller stores there."""
-        if not note_events:
-            return note_events
+    @staticmethod
+    def _ghost_density(note_events):
         max_time = max(e["end"] for e in note_events)
         density = np.zeros(len(np.linspace(0, max_time, int(max_time * 10))))
         for e in note_events:
             a, b = int(e["start"] * 10), int(e["end"] * 10)
             if a < len(density):
                 density[a:min(b, len(density))] += 1
-        rsi_values = self.rsi(density, period=14) if len(density) else np.zeros(0)
+        return density
+
+    @staticmethod
+    def _ghost_keep(note_events, rsi_values, rsi_threshold):
         kept = []
         for e in note_events:
             i = int(e["start"] * 10)
@@ -128,13 +128,45 @@ class FinancialPitchAnalyzer:
                 kept.append(e)
         return kept
 
+    def filter_ghost_notes_rsi(self, note_events, rsi_threshold=70):
+        """financial_analysis.py:322-362, including its mixed units: `start`/`end` are scaled by 10 as if
+        they were seconds whatever the caller stores there."""
+        if not note_events:
+            return note_events
+        density = self._ghost_density(note_events)
+        rsi_values = self.rsi(density, period=14) if len(density) else np.zeros(0)
+        return self._ghost_keep(note_events, rsi_values, rsi_threshold)
+
+    def filter_ghost_notes_rsi_batch(self, event_lists, rsi_threshold=70):
+        """filter_ghost_notes_rsi for several clips: every clip's density track is one series of ONE library call, which
+        returns the two Wilder averages; the RSI value (avg_gain / avg_loss -> 100 - 100 / (1 + rs), the reference's
+        operations) is then formed at the few positions the filter reads."""
+        dens = [self._ghost_density(ev) if ev else np.zeros(0) for ev in event_lists]
+        live = [i for i, d in enumerate(dens) if len(d)]
+        out = list(event_lists)
+        if not live:
+            return out
+        ag, al = _handle(self.device).trend(_lib.TREND_RSI, [dens[i] for i in live], [14, 1], n_out=2)
+        for j, i in enumerate(live):
+            ev = event_lists[i]
+            idx = np.array([int(e["start"] * 10) for e in ev])
+            inside = idx < len(dens[i])
+            g, l = ag[j][idx[inside]], al[j][idx[inside]]
+            with np.errstate(divide="ignore", invalid="ignore"):
+                val = 100 - (100 / (1 + g / l))
+            val = np.where(l == 0, 100.0, val)
+            val = np.where(np.isnan(g), 50.0, val)            # the first `period` positions and tracks shorter than it
+            keep = np.ones(len(ev), bool)
+            keep[inside] = val < rsi_threshold
+            out[i] = [e for e, k in zip(ev, keep) if k]
+        return out
+
     def analyze_pitch_financial(self, f0, voiced_flag, use_advanced_filters=True):
         """-> {'trend', 'articulations', 'slides', 'confidence'}  (financial_analysis.py:368-423)."""
         f0 = np.asarray(f0, dtype=np.float64)
         if use_advanced_filters:
-            trend, _ = multi_filter_consensus(f0, filters=["savgol", "kalman", "holt"])
-        else:
-            trend = self.exponential_moving_average(f0, span=5)
+            return self.analyze_pitch_financial_batch([f0])[0]
+        trend = self.exponential_moving_average(f0, span=5)
         articulations = self.detect_articulation_bollinger(f0, window=10)
         slides = self.detect_slides_macd(f0, threshold=0.3)
         _, upper, lower = self.bollinger_bands(f0, window=10)
@@ -143,3 +175,25 @@ class FinancialPitchAnalyzer:
         confidence = np.zeros_like(f0)
         confidence[ok] = np.where(width[ok] > 0, 1.0 / (1.0 + width[ok]), 1.0)
         return {"trend": trend, "articulations": articulations, "slides": slides, "confidence": confidence}
+
+    def analyze_pitch_financial_batch(self, tracks, labels=True):
+        """analyze_pitch_financial (use_advanced_filters=True) for a list of pitch tracks in ONE library call
+        (AEGIS_TREND_PITCH_ANALYSIS: the consensus filters, both state machines and the band-width confidence, the four
+        sequential walks on four streams at once).  labels=False leaves 'articulations' / 'slides' as int8 code arrays
+        (indices into _ARTICULATIONS / _SLIDES) instead of the reference's lists of strings."""
+        tracks = [np.asarray(t, dtype=np.float64) for t in tracks]
+        for t in tracks:
+            if len(t) < 10:        # bollinger_bands(window=10) on a shorter track raises in the reference (np.convolve 'same')
+                raise IndexError(f"series of {len(t)} samples is shorter than the window 10")
+        coef = scipy.signal.savgol_coeffs(11, 3)[::-1]
+        symmetric = bool(np.all(np.abs(coef - coef[::-1]) <= np.finfo(float).eps))
+        params = [11, int(symmetric), *coef, 1e-5, 1e-1, 0.3, 0.1, 10, 2, 0.3]
+        trend, art, sl, conf = _handle(self.device).trend(_lib.TREND_PITCH_ANALYSIS, tracks, params, n_out=4,
+                                                           out_dtype=[np.float64, np.int8, np.int8, np.float64])
+        out = []
+        for i in range(len(tracks)):
+            a, s_ = art[i], sl[i]
+            if labels:
+                a, s_ = [_ARTICULATIONS[c] for c in a], [_SLIDES[c] for c in s_]
+            out.append({"trend": trend[i], "articulations": a, "slides": s_, "confidence": conf[i]})
+        return out

@@ -35,11 +35,17 @@ class GuitarSpecificFilters:
         return out_f0, out_v
 
     @staticmethod
-    def detect_palm_mute(S_dB, hop_length, sr, duration_ms=50):
-        """Low-half / high-half mean ratio above 2 for at most duration_ms (guitar_specific.py:60-103)."""
-        n_mels, F = S_dB.shape
-        mid = n_mels // 2
-        ratio = np.mean(S_dB[:mid, :], axis=0) / (np.mean(S_dB[mid:, :], axis=0) + 1e-6)
+    def detect_palm_mute(S_dB, hop_length, sr, duration_ms=50, _means=None):
+        """Low-half / high-half mean ratio above 2 for at most duration_ms (guitar_specific.py:60-103).
+        _means = (low-half, high-half) column means when the analysis delivered them (aegis_outputs.sdb_col_means)."""
+        if _means is None:
+            n_mels, F = S_dB.shape
+            mid = n_mels // 2
+            lo, hi = np.mean(S_dB[:mid, :], axis=0), np.mean(S_dB[mid:, :], axis=0)
+        else:
+            lo, hi = _means
+            F = len(lo)
+        ratio = lo / (hi + 1e-6)
         max_frames = int(duration_ms / ((hop_length / sr) * 1000))
         out = np.zeros(F, dtype=bool)
         for s, e in _runs(ratio > 2.0):
@@ -48,11 +54,11 @@ class GuitarSpecificFilters:
         return out
 
     @staticmethod
-    def detect_rake_enhanced(S_dB, hop_length, sr, rake_mask_basic):
+    def detect_rake_enhanced(S_dB, hop_length, sr, rake_mask_basic, _level=None):
         """Adds frames after a >10 dB jump of the mean level when the next 30 ms fall on average
-        (guitar_specific.py:105-141)."""
+        (guitar_specific.py:105-141).  _level = np.mean(S_dB, axis=0) when the analysis delivered it."""
         out = np.asarray(rake_mask_basic).copy()
-        level = np.mean(S_dB, axis=0)
+        level = np.mean(S_dB, axis=0) if _level is None else _level
         diff = np.diff(level, prepend=level[0])
         span = int(30 / ((hop_length / sr) * 1000))
         for i in np.flatnonzero(diff[1:] > 10) + 1:
@@ -96,3 +102,14 @@ def apply_guitar_filters(f0, voiced_flag, S_dB, hop_length, sr, rake_mask):
     f0_f, voiced_f = g.filter_subharmonic_noise(f0, voiced_flag, fmin_hz=82.4)
     return {"f0": f0_f, "voiced": voiced_f, "rake_mask": g.detect_rake_enhanced(S_dB, hop_length, sr, rake_mask),
             "mute_mask": g.detect_palm_mute(S_dB, hop_length, sr), "distortion": g.classify_distortion_level(S_dB)}
+
+
+def apply_guitar_filters_from_means(f0, voiced_flag, col_means, hop_length, sr, rake_mask):
+    """apply_guitar_filters on the three column means of the dB image the library computes beside it
+    (col_means = (all rows, low half, high half), aegis_outputs.sdb_col_means) instead of the image itself; the
+    'distortion' label, which needs the whole image and which no caller of the engine reads, is left out."""
+    g = GuitarSpecificFilters
+    f0_f, voiced_f = g.filter_subharmonic_noise(f0, voiced_flag, fmin_hz=82.4)
+    return {"f0": f0_f, "voiced": voiced_f,
+            "rake_mask": g.detect_rake_enhanced(None, hop_length, sr, rake_mask, _level=col_means[0]),
+            "mute_mask": g.detect_palm_mute(None, hop_length, sr, _means=(col_means[1], col_means[2]))}

@@ -46,20 +46,99 @@ def adaptive_confidence_threshold(confidence_values, method="bollinger"):
     return 0.5
 
 
-def get_midi_events_financial(rake_mask, f0, voiced_flag, active_probs, rms, sr, hop_length,
-                              confidence_threshold=None, verbose=False, **kwargs):
+def _note_events_loop(sounding, pitch, level_db, combined, confidence_threshold, track, analyzer, artic=None, slide=None):
+    """The reference's frame loop as written (midi_logic_financial.py:205-262).  Runs the legacy path
+    (use_financial=False: the technique of a closed note comes from detect_articulations_financial, and a note still
+    open at the end gets no 'technique' key at all); with `artic` / `slide` label lists it is the financial path, kept
+    as the check of _note_events_from_frames."""
+    use_financial = artic is not None
+
+    def close(ev, is_last):
+        if use_financial:
+            ev["technique"] = ev.get("financial_artic")
+        elif not is_last:        # the reference forgets the technique of a note still open at the end
+            ev["technique"] = detect_articulations_financial(track, ev["start"], ev["end"], analyzer)
+        return ev
+
+    events, cur = [], None
+    for t in range(len(sounding)):
+        if sounding[t]:
+            a = artic[t] if use_financial else None
+            if cur is not None and cur["note"] == pitch[t]:
+                cur["end"] = t
+                if a and a != "normal":
+                    cur["financial_artic"] = a
+                continue
+            if cur is not None:
+                events.append(close(cur, False))
+            level, conf = level_db[t], combined[t]
+            cur = {"note": int(pitch[t]), "start": t, "end": t, "confidence": conf,
+                   "velocity": int(np.clip((level + 80) * 1.5, 0, 127)),
+                   "track": "main" if conf >= confidence_threshold else "safe",
+                   "financial_artic": a, "financial_slide": slide[t] if use_financial else None}
+        elif cur is not None:
+            events.append(close(cur, False))
+            cur = None
+    if cur is not None:
+        events.append(close(cur, True))
+    return events
+
+
+_ARTIC = (None, "normal", "bend", "vibrato", "noise")          # financial.py codes
+_SLIDE = (None, "normal", "slide_up", "slide_down")
+_ARTIC_CODE = {a: i for i, a in enumerate(_ARTIC)}
+_SLIDE_CODE = {a: i for i, a in enumerate(_SLIDE)}
+
+
+def _codes(labels, table):
+    if isinstance(labels, np.ndarray) and labels.dtype.kind in "iu":
+        return labels
+    return np.fromiter((table[x] for x in labels), dtype=np.int8, count=len(labels))
+
+
+def _note_events_from_frames(sounding, pitch, level_db, combined, confidence_threshold, artic, slide):
+    """The frame loop of get_midi_events_financial (midi_logic_financial.py:205-262) as array passes, for the financial
+    path: notes are the maximal runs of sounding frames with one pitch; a note's fields come from its first frame,
+    its `financial_artic` is the LAST label other than None / 'normal' among its later frames (the first frame's label
+    when there is none), and `technique` copies it when the note closes."""
+    n = len(sounding)
+    if n == 0 or not sounding.any():
+        return []
+    key = np.where(sounding, pitch, np.iinfo(np.int64).min)
+    change = np.flatnonzero(key[1:] != key[:-1]) + 1
+    starts = np.concatenate(([0], change))
+    ends = np.concatenate((change, [n])) - 1
+    keep = sounding[starts]
+    starts, ends = starts[keep], ends[keep]
+    special = np.where(artic >= 2, np.arange(n), -1)
+    last_special = np.maximum.accumulate(special)[ends]
+    a_code = np.where(last_special > starts, artic[np.maximum(last_special, 0)], artic[starts])
+    conf = combined[starts]
+    level = level_db[starts]
+    velocity = np.clip((level + 80) * 1.5, 0, 127).astype(np.int64)
+    return [{"note": nt, "start": s, "end": e, "confidence": c, "velocity": v,
+             "track": "main" if c >= confidence_threshold else "safe",
+             "financial_artic": _ARTIC[a], "financial_slide": _SLIDE[sl], "technique": _ARTIC[a]}
+            for nt, s, e, c, v, a, sl in zip(pitch[starts].tolist(), starts.tolist(), ends.tolist(), conf, velocity.tolist(),
+                                              a_code.tolist(), slide[starts].tolist())]
+
+
+def _financial_notes(rake_mask, f0, voiced_flag, active_probs, rms, sr, hop_length, confidence_threshold, say, analysis,
+                     kwargs):
+    """get_midi_events_financial up to and including the merge of neighbouring notes (midi_logic_financial.py:117-290).
+    -> (events, confidence_threshold, analyzer)"""
     noise_gate_db = kwargs.get("noise_gate_db", -40)
     sustain_ms = kwargs.get("sustain_ms", 50)
     min_note_duration_ms = kwargs.get("min_note_duration_ms", 50)
     use_financial = kwargs.get("use_financial", True)
-    say = print if verbose else (lambda *a, **k: None)
     f0 = np.asarray(f0, dtype=np.float64)
     voiced_flag = np.asarray(voiced_flag, dtype=bool)
     n = len(f0)
 
     analyzer = FinancialPitchAnalyzer(sr=sr, hop_length=hop_length)
     if use_financial:
-        analysis = analyzer.analyze_pitch_financial(np.where(voiced_flag, f0, np.nan), voiced_flag)
+        if analysis is None:
+            analysis = analyzer.analyze_pitch_financial_batch([np.where(voiced_flag, f0, np.nan)], labels=False)[0]
         track = analysis["trend"]
         articulations, slides = analysis["articulations"], analysis["slides"]
         combined = active_probs * 0.5 + analysis["confidence"] * 0.5
@@ -85,36 +164,13 @@ def get_midi_events_financial(rake_mask, f0, voiced_flag, active_probs, rms, sr,
     if sounding.any():
         pitch[sounding] = np.rint(hz_to_midi(track[sounding])).astype(np.int64)
 
-    def close(ev, is_last):
-        if use_financial:
-            ev["technique"] = ev.get("financial_artic")
-        elif not is_last:        # the reference forgets the technique of a note still open at the end
-            ev["technique"] = detect_articulations_financial(track, ev["start"], ev["end"], analyzer)
-        return ev
-
-    events, cur = [], None
-    for t in range(len(track)):
-        if sounding[t]:
-            artic = articulations[t] if use_financial else None
-            if cur is not None and cur["note"] == pitch[t]:
-                cur["end"] = t
-                if artic and artic != "normal":
-                    cur["financial_artic"] = artic
-                continue
-            if cur is not None:
-                events.append(close(cur, False))
-            level, conf = level_db[t], combined[t]
-            cur = {"note": int(pitch[t]), "start": t, "end": t, "confidence": conf,
-                   "velocity": int(np.clip((level + 80) * 1.5, 0, 127)),
-                   "track": "main" if conf >= confidence_threshold else "safe",
-                   "financial_artic": artic, "financial_slide": slides[t] if use_financial else None}
-        elif cur is not None:
-            events.append(close(cur, False))
-            cur = None
-    if cur is not None:
-        events.append(close(cur, True))
+    if use_financial:
+        events = _note_events_from_frames(sounding, pitch, level_db, combined, confidence_threshold,
+                                          _codes(articulations, _ARTIC_CODE), _codes(slides, _SLIDE_CODE))
+    else:
+        events = _note_events_loop(sounding, pitch, level_db, combined, confidence_threshold, track, analyzer)
     if not events:
-        return []
+        return [], confidence_threshold, analyzer
 
     events = [e for e in events if e["end"] - e["start"] >= min_frames]
     if len(events) > 1:
@@ -126,10 +182,12 @@ def get_midi_events_financial(rake_mask, f0, voiced_flag, active_probs, rms, sr,
             else:
                 out.append(e)
         events = out
+    return events, confidence_threshold, analyzer
 
-    if use_financial and len(events) > 10:
-        events = analyzer.filter_ghost_notes_rsi(events, rsi_threshold=70)
 
+def _harmonic_stage(events, confidence_threshold, sr, hop_length, say, kwargs):
+    """The harmonic filter at the end of get_midi_events_financial (midi_logic_financial.py:330-388)."""
+    use_financial = kwargs.get("use_financial", True)
     if use_financial and kwargs.get("use_harmonic_filter", True) and len(events) > 5:
         hz = HarmonicAnalyzer()
         frame_ms = (hop_length / sr) * 1000
@@ -157,3 +215,39 @@ def get_midi_events_financial(rake_mask, f0, voiced_flag, active_probs, rms, sr,
             events[0]["key_info"] = key_info        # IndexError when everything was out of scale (Q11)
     say(f"[Financial] events: {len(events)}")
     return events
+
+
+def get_midi_events_financial(rake_mask, f0, voiced_flag, active_probs, rms, sr, hop_length,
+                              confidence_threshold=None, verbose=False, **kwargs):
+    say = print if verbose else (lambda *a, **k: None)
+    events, thr, analyzer = _financial_notes(rake_mask, f0, voiced_flag, active_probs, rms, sr, hop_length,
+                                             confidence_threshold, say, None, kwargs)
+    if not events:
+        return []
+    if kwargs.get("use_financial", True) and len(events) > 10:
+        events = analyzer.filter_ghost_notes_rsi_batch([events], rsi_threshold=70)[0]
+    return _harmonic_stage(events, thr, sr, hop_length, say, kwargs)
+
+
+def get_midi_events_financial_batch(clips, sr, hop_length, confidence_threshold=None, verbose=False, **kwargs):
+    """get_midi_events_financial for several clips (each a dict with rake_mask, f0, voiced_flag, active_probs, rms):
+    ONE fused pitch-analysis call over all the pitch tracks (FinancialPitchAnalyzer.analyze_pitch_financial_batch) and
+    ONE RSI call over all the ghost-note density tracks instead of eight library calls per clip; the per-note logic is
+    the single-clip function's.  -> list of event lists."""
+    say = print if verbose else (lambda *a, **k: None)
+    use_financial = kwargs.get("use_financial", True)
+    analyses = [None] * len(clips)
+    if use_financial and clips:
+        an = FinancialPitchAnalyzer(sr=sr, hop_length=hop_length)
+        tracks = [np.where(np.asarray(c["voiced_flag"], bool), np.asarray(c["f0"], np.float64), np.nan) for c in clips]
+        analyses = an.analyze_pitch_financial_batch(tracks, labels=False)
+    staged = [_financial_notes(c["rake_mask"], c["f0"], c["voiced_flag"], c["active_probs"], c["rms"], sr, hop_length,
+                               confidence_threshold, say, a, kwargs) for c, a in zip(clips, analyses)]
+    lists = [ev for ev, _, _ in staged]
+    if use_financial:
+        need = [i for i, ev in enumerate(lists) if len(ev) > 10]
+        if need:
+            kept = FinancialPitchAnalyzer(sr=sr, hop_length=hop_length).filter_ghost_notes_rsi_batch([lists[i] for i in need])
+            for i, ev in zip(need, kept):
+                lists[i] = ev
+    return [_harmonic_stage(ev, thr, sr, hop_length, say, kwargs) if ev else [] for ev, (_, thr, _) in zip(lists, staged)]

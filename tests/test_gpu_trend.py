@@ -94,6 +94,7 @@ def test_analyze_pitch_financial():
 
 def test_ghost_note_filter_matches_reference():
     cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "v2_harmonic_golden.json")))
+    lists, want = [], []
     for c in cases:
         if not c["midi"]:
             continue
@@ -101,6 +102,11 @@ def test_ghost_note_filter_matches_reference():
                   for n, t, d in zip(c["midi"], c["times"], c["durs"])]
         kept = an.filter_ghost_notes_rsi(events, rsi_threshold=70)
         assert [events.index(e) for e in kept] == c["ghost_kept"], c["name"]
+        lists.append(events)
+        want.append(c["ghost_kept"])
+    # all the clips' density tracks in ONE call, the RSI formed from the two Wilder averages at the positions read
+    for events, kept, w in zip(lists, an.filter_ghost_notes_rsi_batch(lists + [[]])[:-1], want):
+        assert [events.index(e) for e in kept] == w
     assert an.filter_ghost_notes_rsi([]) == []
 
 
@@ -116,3 +122,27 @@ def test_ragged_batch_equals_single_series():
     with pytest.raises(_lib.AegisError):
         h.trend(99, series, [1])
     h.close()
+
+
+def test_fused_pitch_analysis_batch_equals_the_single_ops():
+    """AEGIS_TREND_PITCH_ANALYSIS (analyze_pitch_financial as one call, four streams) over a ragged batch == the single
+    ops series by series, bit for bit: trend = consensus median of savgol / kalman / holt, Bollinger articulation codes,
+    MACD slide codes, band-width confidence."""
+    series = [G[f"{n}/x"] for n in NAMES if len(G[f"{n}/x"]) >= 26]
+    assert len(series) >= 3
+    res = an.analyze_pitch_financial_batch(series)
+    raw = an.analyze_pitch_financial_batch(series, labels=False)
+    for s, r, q in zip(series, res, raw):
+        med, _ = multi_filter_consensus(s)
+        exact(r["trend"], med, "fused trend")
+        assert r["articulations"] == an.detect_articulation_bollinger(s, window=10)
+        assert r["slides"] == an.detect_slides_macd(s, threshold=0.3)
+        _, up, lo = an.bollinger_bands(s, window=10)
+        w = up - lo
+        ok = ~np.isnan(s) & ~np.isnan(w)
+        conf = np.zeros_like(s)
+        conf[ok] = np.where(w[ok] > 0, 1.0 / (1.0 + w[ok]), 1.0)
+        exact(r["confidence"], conf, "fused confidence")
+        assert q["articulations"].dtype == np.int8 and [ART[c] for c in q["articulations"]] == r["articulations"]
+    with pytest.raises(IndexError):
+        an.analyze_pitch_financial_batch([np.ones(5)])

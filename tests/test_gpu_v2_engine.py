@@ -61,3 +61,35 @@ def test_engine_end_to_end(tmp_path):
     silent = str(tmp_path / "silent.wav")
     audio_io.write_wav(silent, np.zeros(22050, np.float32), 22050)
     assert eng.audio_to_midi_financial(silent, mid) is None
+
+
+def test_batched_v2_engine_equals_clip_by_clip():
+    """AegisFinancialEngine.analyze_arrays (one GPU batch, column means of the dB image from the GPU, fused pitch
+    analysis, one RSI call) == analyze_array per clip, which test_financial_events_match_reference pins to the reference."""
+    clips = [signals.guitar_clip(10.0, sr=22050, seed=21), signals.polyphonic_clip(6.0, sr=22050, seed=5),
+             signals.guitar_test_track(sr=22050), signals.c_major_scale(22050), signals.guitar_clip(14.0, sr=22050, seed=3)]
+    eng = AegisFinancialEngine()
+    for kw in ({}, {"confidence_threshold": 0.6, "min_note_duration_ms": 80}, {"use_harmonic_filter": False, "sustain_ms": 120},
+               {"use_guitar_filters": False}):
+        batch = eng.analyze_arrays(clips, **kw)
+        assert len(batch) == len(clips) and sum(len(b) for b in batch) > 10
+        for y, ev in zip(clips, batch):
+            one = eng.analyze_array(y, **kw)
+            assert len(ev) == len(one)
+            for a, b in zip(ev, one):
+                assert set(a) == set(b)
+                for k in b:
+                    if k == "key_info":
+                        assert (a[k]["key"], a[k]["mode"]) == (b[k]["key"], b[k]["mode"])
+                    else:
+                        assert a[k] == b[k] or (a[k] != a[k] and b[k] != b[k]), (k, a[k], b[k])
+    # the column means of the dB image equal NumPy's on the image itself, bit for bit
+    h = eng.handle
+    res, bufs, off = h.analyze_batch(clips[:2], want_sdb=True, want_col_means=True, concatenated=True)
+    F = int(off[-1])
+    for i, r in enumerate(res):
+        a, b = int(off[i]), int(off[i + 1])
+        S = r["S_dB"]
+        np.testing.assert_array_equal(bufs["sdb_col_means"][a:b], np.mean(S, axis=0))
+        np.testing.assert_array_equal(bufs["sdb_col_means"][F + a:F + b], np.mean(S[:64], axis=0))
+        np.testing.assert_array_equal(bufs["sdb_col_means"][2 * F + a:2 * F + b], np.mean(S[64:], axis=0))

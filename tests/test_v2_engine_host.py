@@ -39,3 +39,25 @@ def test_adaptive_threshold():
         assert float(adaptive_confidence_threshold(c, "bollinger")) == m["thr_boll"]
         assert float(adaptive_confidence_threshold(c, "percentile")) == m["thr_pct"]
     assert adaptive_confidence_threshold(np.zeros(4)) == 0.5
+
+
+def test_vectorised_note_frames_equal_the_reference_loop():
+    """The financial path's frame loop (midi_logic_financial.py:205-262) as array passes == the loop as written."""
+    from spectrogram_midi_amd import midi_logic_financial as m
+    rng = np.random.default_rng(1)
+    for case in range(200):
+        n = int(rng.integers(1, 300))
+        sounding = rng.random(n) < rng.choice([0.3, 0.8, 1.0])
+        pitch = np.repeat(rng.integers(40, 80, n // 5 + 1), 5)[:n].astype(np.int64)
+        level = (rng.random(n) * -60).astype(np.float32)
+        comb = rng.random(n)
+        art = rng.choice(5, n, p=[.1, .6, .1, .1, .1]).astype(np.int8)
+        sl = rng.integers(0, 4, n).astype(np.int8)
+        a = m._note_events_from_frames(sounding, pitch, level, comb, 0.5, art, sl)
+        b = m._note_events_loop(sounding, pitch, level, comb, 0.5, None, None, artic=[m._ARTIC[c] for c in art],
+                                slide=[m._SLIDE[c] for c in sl])
+        assert a == b, case
+        for x, y in zip(a, b):
+            assert [type(x[k]) for k in y] == [type(y[k]) for k in y]
+    assert m._note_events_from_frames(np.zeros(0, bool), np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0), 0.5,
+                                      np.zeros(0, np.int8), np.zeros(0, np.int8)) == []
