@@ -232,17 +232,28 @@ def run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum):
     handle = _lib.Handle(sample_rate=SR, hop_length=HOP, device=dev.index)
     audio_seconds = sum(len(c) for c in clips) / SR
     frames = sum(handle.frames_for(len(c)) for c in clips)
+    # inputs resident in HBM, result left in HBM: the device entry (aegis_cqt_device); the host-buffer entry beside it
+    offs = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    d_out = torch.empty(frames * 84, dtype=torch.float32, device=dev)
     for _ in range(args.warmup):
-        handle.cqt(clips)
+        handle.cqt_device(d_pcm.data_ptr(), offs, d_out.data_ptr())
     handle.set_profiling(True)
     kms = 0.0
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        handle.cqt(clips)
+        handle.cqt_device(d_pcm.data_ptr(), offs, d_out.data_ptr())
         kms += handle.kernel_ms("cqt")
     fence()
-    wall = time.perf_counter() - t0
+    wall_dev = time.perf_counter() - t0
+    handle.cqt(clips)
+    fence()
+    t0 = time.perf_counter()
+    handle.cqt(clips)
+    fence()
+    wall = (time.perf_counter() - t0) * args.steps
+    wall_dev = reduce_max(wall_dev)
     kernel_s = reduce_max(kms * 1e-3)
     wall = reduce_max(wall)
     total_audio = reduce_sum(audio_seconds)
@@ -262,16 +273,18 @@ def run_cqt(args, rank, world, dev, fence, reduce_max, reduce_sum):
     per_launch_s = kernel_s / args.steps
     return {
         "metric": "audio-seconds through the 84-bin CQT filter bank/sec (44.1 kHz, hop=512)",
-        "value": round(total_audio * args.steps / kernel_s, 2), "unit": "audio-seconds/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(per_launch_s * 1e3, 3),
+        "value": round(total_audio * args.steps / wall_dev, 2), "unit": "audio-seconds/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(wall_dev / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "configs[2]: 64 x 30 s polyphonic clips (3 Karplus-Strong voices), CQT C1 + 84 bins, 12 per octave",
                    "clips_per_gpu": 64, "clip_seconds": 30.0, "sample_rate": SR, "hop_length": HOP, "frames_per_gpu": frames,
-                   "timed": "cqt_slide_kernel by HIP events on the handle's stream; host-inclusive wall beside it"},
+                   "timed": "aegis_cqt_device (PCM and magnitudes resident in HBM), wall clock between the fences; the kernel's "
+                            "own HIP-event time feeds the roofline; the host-buffer entry's wall time beside it"},
         "roofline": {"bound": "mfma", "kernel": "cqt_slide", "achieved": round(issued / per_launch_s / 1e12, 2),
                      "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(issued / per_launch_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "frac_useful": round(useful / per_launch_s / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
                      "issued_flop_per_launch": int(issued), "useful_flop_per_launch": int(useful), "traffic": None},
+        "kernel_ms": round(per_launch_s * 1e3, 3),
         "host_inclusive_ms_per_step": round(wall / args.steps * 1e3, 3),
     }
 

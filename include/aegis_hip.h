@@ -134,6 +134,12 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
  * 7 x 36 = 252 bins run as three launches of 11 row tiles); the longest atom may span up to 131 072 taps.  Blocking. */
 int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
               int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out);
+/* The same with the PCM and the result resident in device memory (clip c = d_pcm[sample_offsets[c] .. sample_offsets[c+1]),
+ * `sample_offsets` a host array of n_clips + 1 entries; d_mag_out as mag_out).  Enqueued on `stream` (NULL = the handle's);
+ * returns without waiting for the kernel unless sync != 0. */
+int aegis_cqt_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets, int32_t n_clips,
+                     int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *d_mag_out,
+                     void *stream, int32_t sync);
 
 /* --- incremental analysis of one clip (BASELINE.json configs[4]; the reference has no streaming path:
  * financial_app_realtime.py analyses whole files).  Samples are pushed in any chunk sizes; every frame whose

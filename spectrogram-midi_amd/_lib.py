@@ -41,7 +41,7 @@ class Outputs(C.Structure):
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
            "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend",
-           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt",
+           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt", "aegis_cqt_device",
            "aegis_extract_events", "aegis_render_smf", "aegis_events_last_error")
 
 _lib = None
@@ -88,6 +88,9 @@ def load():
     lib.aegis_cqt.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
                               C.c_double, C.c_double, C.c_void_p]
     lib.aegis_cqt.restype = C.c_int
+    lib.aegis_cqt_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.c_double,
+                                     C.c_double, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.aegis_cqt_device.restype = C.c_int
     lib.aegis_set_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_set_table.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -318,6 +321,14 @@ class Handle:
             res.append(out[o:o + Fc * n_bins].reshape(n_bins, Fc).copy())
             o += Fc * n_bins
         return res
+
+    def cqt_device(self, d_pcm_ptr, sample_offsets, d_out_ptr, n_bins=84, bins_per_octave=12, fmin=32.70319566257483,
+                   filter_scale=1.0, stream=None, sync=True):
+        """aegis_cqt_device: PCM and |CQT| resident in device memory (raw pointers as ints)."""
+        off = np.ascontiguousarray(sample_offsets, dtype=np.int64)
+        self._check(self.lib.aegis_cqt_device(self._h, C.c_void_p(int(d_pcm_ptr)), off.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              len(off) - 1, n_bins, bins_per_octave, float(fmin), float(filter_scale),
+                                              C.c_void_p(int(d_out_ptr)), C.c_void_p(stream or 0), 1 if sync else 0))
 
     def open_stream(self, max_seconds=600.0):
         return Stream(self, int(max_seconds * self.sr))

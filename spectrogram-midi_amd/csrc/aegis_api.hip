@@ -76,6 +76,8 @@ struct aegis_handle {
     uint32_t chunk_gen = 0;                   // generation of the chunk flags of a persistent Viterbi launch
     int test_drop_signal = -1;
     bool persist_gave_up = false;
+    int persist_cooldown = 0;                 // calls left on the one-launch-per-chunk schedule after a give-up; then the single launch is tried again
+    bool persistent_wanted = true;            // what AEGIS_VITERBI_PERSISTENT asked for
     int64_t persistent_fallbacks = 0;         // calls repeated with one launch per chunk (aegis_debug_fetch "persistent_fallbacks")
     bool persist_pending = false;             // a persistent launch ran since the abort flag was last read
     bool persistent = true;                   // one Viterbi launch per balanced pass (AEGIS_VITERBI_PERSISTENT=0: one per chunk)
@@ -283,7 +285,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_ENDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->balanced_ends = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
-    if (const char *e = std::getenv("AEGIS_VITERBI_PERSISTENT")) h->persistent = std::atoi(e) != 0;
+    if (const char *e = std::getenv("AEGIS_VITERBI_PERSISTENT")) h->persistent = h->persistent_wanted = std::atoi(e) != 0;
     if (const char *e = std::getenv("AEGIS_TEST_DROP_CHUNK_SIGNAL")) h->test_drop_signal = std::atoi(e);
     if (const char *e = std::getenv("AEGIS_RAMP_K")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 64) h->ramp_k = (int)v; }
     if (const char *e = std::getenv("AEGIS_CU_SPLIT")) h->split_limit = std::atoi(e);
@@ -415,12 +417,16 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
     try {
     if (!h) return AEGIS_ERR_INVALID;
     std::lock_guard<std::mutex> lock(h->mu);
+    if (!h->persistent && h->persistent_wanted && h->persist_cooldown > 0 && --h->persist_cooldown == 0)
+        h->persistent = true;                 // the give-up is not for good: whatever serialised the kernels may be gone
     int rc = analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
     if (rc != AEGIS_OK && h->persist_gave_up) {
         // The single Viterbi launch of a balanced pass found the frame stage not running beside it (a profiler collecting
-        // counters serialises kernels, for one): this handle goes back to one launch per chunk and the call is repeated.
+        // counters serialises kernels, for one): this handle goes back to one launch per chunk for the next 16 calls and
+        // the call is repeated.
         h->persist_gave_up = false;
         h->persistent = false;
+        h->persist_cooldown = 16;
         ++h->persistent_fallbacks;
         rc = analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
     }
@@ -756,6 +762,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             p.chunk_gen = ++h->chunk_gen;
             if (p.chunk_gen == 0) p.chunk_gen = ++h->chunk_gen;
             p.abort_flag = static_cast<uint32_t *>(h->abort_flag.p);
+            // bound of one chunk wait: a chunk's frame stage takes well under a millisecond per 10 k frames, so 0.1 s plus
+            // 0.1 s per million frames of the pass is two orders of magnitude of slack, and a pass that cannot overlap
+            // (kernels serialised) costs that much once instead of 1.5 s
+            p.wait_ticks = (uint64_t)std::min<int64_t>(150000000, 10000000 + fp * 10);
             h->persist_pending = true;
         }
         for (int k = 0; k < nk; ++k) {
@@ -932,20 +942,12 @@ int aegis_rake_patterns(aegis_handle *h, const float *S_dB, int32_t n_mels, int6
     } catch (...) { return abi_fail(h); }
 }
 
-int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
-              int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out) {
-    try {
-    if (!h) return AEGIS_ERR_INVALID;
-    if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !mag_out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
-    if (n_clips == 0) return AEGIS_OK;
-    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+// the bank of (n_bins, bins_per_octave, fmin, filter_scale), built and uploaded on first use
+static int cqt_bank_locked(aegis_handle *h, int32_t &n_bins, int32_t &bins_per_octave, double &fmin, double &filter_scale, hipStream_t s) {
     if (n_bins == 0) n_bins = 84;
     if (bins_per_octave == 0) bins_per_octave = 12;
     if (!(fmin > 0)) fmin = 32.70319566257483;            // note_to_hz('C1')
     if (!(filter_scale > 0)) filter_scale = 1.0;
-    std::lock_guard<std::mutex> lock(h->mu);
-    HIPCHK(h, hipSetDevice(h->device));
-    hipStream_t s = h->stream;
     CqtBank &b = h->cqt_bank;
     if (b.n_bins != n_bins || b.bins_per_octave != bins_per_octave || b.fmin != fmin || b.filter_scale != filter_scale || !b.dev) {
         HIPCHK(h, hipStreamSynchronize(s));
@@ -955,34 +957,90 @@ int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples
         HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&b.dev), b.data.size() * 4));
         HIPCHK(h, hipMemcpy(b.dev, b.data.data(), b.data.size() * 4, hipMemcpyHostToDevice));
     }
-    std::vector<int64_t> soff(n_clips + 1, 0), foff(n_clips + 1, 0), toff(n_clips + 1, 0);
+    return AEGIS_OK;
+}
+
+// clip geometry on the device + the launch; d_pcm and d_out are device pointers
+static int cqt_launch_locked(aegis_handle *h, const float *d_pcm, const int64_t *soff, int32_t n_clips, float *d_out, hipStream_t s,
+                             int64_t *total_frames) {
+    std::vector<int64_t> foff(n_clips + 1, 0), toff(n_clips + 1, 0);
     for (int i = 0; i < n_clips; ++i) {
-        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) { h->err = "bad clip " + std::to_string(i); return AEGIS_ERR_INVALID; }
-        soff[i + 1] = soff[i] + n_samples[i];
-        foff[i + 1] = foff[i] + 1 + n_samples[i] / h->tab.hop;
-        toff[i + 1] = toff[i] + (1 + n_samples[i] / h->tab.hop + kCqtSlideFrames - 1) / kCqtSlideFrames;
+        const int64_t n = soff[i + 1] - soff[i];
+        if (n < 0) { h->err = "sample_offsets must be non-decreasing"; return AEGIS_ERR_INVALID; }
+        foff[i + 1] = foff[i] + 1 + n / h->tab.hop;
+        toff[i + 1] = toff[i] + (1 + n / h->tab.hop + kCqtSlideFrames - 1) / kCqtSlideFrames;
     }
-    const int64_t F = foff[n_clips];
     int rc;
-    if ((rc = ensure(h, h->q_pcm, (size_t)std::max<int64_t>(soff[n_clips], 1) * 4)) != AEGIS_OK) return rc;
     if ((rc = ensure(h, h->q_soff, (n_clips + 1) * 8)) != AEGIS_OK) return rc;
     if ((rc = ensure(h, h->q_foff, (n_clips + 1) * 8)) != AEGIS_OK) return rc;
     if ((rc = ensure(h, h->q_toff, (n_clips + 1) * 8)) != AEGIS_OK) return rc;
+    // (pageable host vectors: the copies complete before hipMemcpyAsync returns)
+    HIPCHK(h, hipMemcpyAsync(h->q_soff.p, soff, (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->q_foff.p, foff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->q_toff.p, toff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));         // ... but the vectors die with this frame: make it certain
+    CqtArgs a{d_pcm, static_cast<const int64_t *>(h->q_soff.p), static_cast<const int64_t *>(h->q_foff.p), n_clips,
+              foff[n_clips], h->tab.hop, d_out};
+    if (h->profiling) { for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); } h->events.clear(); }
+    begin_event(h, "cqt", s); launch_cqt(a, h->cqt_bank, static_cast<const int64_t *>(h->q_toff.p), toff[n_clips], s); end_event(h, s);
+    HIPCHK(h, hipGetLastError());
+    *total_frames = foff[n_clips];
+    return AEGIS_OK;
+}
+
+int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
+              int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *mag_out) {
+    try {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !mag_out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    if (n_clips == 0) return AEGIS_OK;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = cqt_bank_locked(h, n_bins, bins_per_octave, fmin, filter_scale, s)) != AEGIS_OK) return rc;
+    std::vector<int64_t> soff(n_clips + 1, 0);
+    int64_t F = 0;
+    for (int i = 0; i < n_clips; ++i) {
+        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) { h->err = "bad clip " + std::to_string(i); return AEGIS_ERR_INVALID; }
+        soff[i + 1] = soff[i] + n_samples[i];
+        F += 1 + n_samples[i] / h->tab.hop;
+    }
+    if ((rc = ensure(h, h->q_pcm, (size_t)std::max<int64_t>(soff[n_clips], 1) * 4)) != AEGIS_OK) return rc;
     if ((rc = ensure(h, h->q_out, (size_t)F * n_bins * 4)) != AEGIS_OK) return rc;
     for (int i = 0; i < n_clips; ++i)
         if (n_samples[i] > 0)
             HIPCHK(h, hipMemcpyAsync(static_cast<float *>(h->q_pcm.p) + soff[i], pcm[i], n_samples[i] * 4, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->q_soff.p, soff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->q_foff.p, foff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(h->q_toff.p, toff.data(), (n_clips + 1) * 8, hipMemcpyHostToDevice, s));
-    CqtArgs a{static_cast<const float *>(h->q_pcm.p), static_cast<const int64_t *>(h->q_soff.p),
-              static_cast<const int64_t *>(h->q_foff.p), n_clips, F, h->tab.hop, static_cast<float *>(h->q_out.p)};
-    if (h->profiling) { for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); } h->events.clear(); }
-    begin_event(h, "cqt", s); launch_cqt(a, b, static_cast<const int64_t *>(h->q_toff.p), toff[n_clips], s); end_event(h, s);
-    HIPCHK(h, hipGetLastError());
+    int64_t Fd = 0;
+    if ((rc = cqt_launch_locked(h, static_cast<const float *>(h->q_pcm.p), soff.data(), n_clips, static_cast<float *>(h->q_out.p), s, &Fd)) != AEGIS_OK) return rc;
     HIPCHK(h, hipMemcpyAsync(mag_out, h->q_out.p, (size_t)F * n_bins * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     if (h->profiling) collect_events(h);
+    return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
+}
+
+int aegis_cqt_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets, int32_t n_clips,
+                     int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *d_mag_out,
+                     void *stream, int32_t sync) {
+    try {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_clips < 0 || (n_clips > 0 && (!sample_offsets || !d_mag_out))) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    if (n_clips == 0) return AEGIS_OK;
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    if (sample_offsets[n_clips] > sample_offsets[0] && !d_pcm) { h->err = "d_pcm == NULL"; return AEGIS_ERR_INVALID; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : h->stream;
+    int rc;
+    if ((rc = cqt_bank_locked(h, n_bins, bins_per_octave, fmin, filter_scale, s)) != AEGIS_OK) return rc;
+    int64_t F = 0;
+    if ((rc = cqt_launch_locked(h, d_pcm, sample_offsets, n_clips, d_mag_out, s, &F)) != AEGIS_OK) return rc;
+    if (sync) {
+        HIPCHK(h, hipStreamSynchronize(s));
+        if (h->profiling) collect_events(h);
+    }
     return AEGIS_OK;
     } catch (...) { return abi_fail(h); }
 }
@@ -1121,8 +1179,16 @@ static int stream_open_locked(aegis_handle *h, int64_t max_samples, aegis_stream
     HIPCHK(h, hipStreamSynchronize(h->stream));
     if (hipHostMalloc(reinterpret_cast<void **>(&st->pin_samples), 8192 * 4, hipHostMallocDefault) != hipSuccess) st->pin_samples = nullptr;
     if (hipHostMalloc(reinterpret_cast<void **>(&st->pin_result), 256, hipHostMallocDefault) != hipSuccess) st->pin_result = nullptr;
-    // AEGIS_STREAM_GRAPH=0 keeps every push on the plain-launch path (isolates the hipGraph replay when profiling)
+    // AEGIS_STREAM_GRAPH=0 keeps every push on the plain-launch path, =1 allows the hipGraph replay.  Unset: the replay,
+    // except under an injected rocprofiler tool -- round 1's SIGSEGV in aegis_stream_push (profiles/
+    // r1_stream_push_sigsegv_symbolised.txt) was the profiler-side packet copy of an INTERCEPTED queue running off the end
+    // of a 1 MiB AQL ring when the HIP runtime rang the doorbell for a graph launch: not this library's memory, and not
+    // something this library can fix, so profiled runs take the plain launches unless told otherwise.
     if (const char *e = std::getenv("AEGIS_STREAM_GRAPH")) st->graph_failed = (e[0] == '0');
+    else {
+        const char *tool = std::getenv("ROCP_TOOL_LIBRARIES"), *pre = std::getenv("LD_PRELOAD");
+        if ((tool && tool[0]) || (pre && std::strstr(pre, "rocprofiler"))) st->graph_failed = true;
+    }
     return AEGIS_OK;
 }
 

@@ -79,6 +79,7 @@ struct PassParams {
     int32_t n_chunks;
     uint32_t chunk_gen;
     uint32_t *abort_flag;
+    uint64_t wait_ticks;         // bound of one chunk wait in 100 MHz wall-clock ticks (0: 1.5 s)
     // workspace (strides in elements)
     double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period
     double *yin;   int32_t yin_stride;   // optional [F][yin_stride]: CMND for lags min..max, written only for the stage tests

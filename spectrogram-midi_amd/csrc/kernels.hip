@@ -285,7 +285,11 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 float4 v = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (q < n4) {
                     if (idx >= 0 && idx + 3 < g0.n) {
-                        v = *reinterpret_cast<const float4 *>(x0 + idx);      // (4-byte aligned is all a global load needs)
+                        // clip offsets are arbitrary, so the address is only 4-byte aligned: the vector type says so (the
+                        // load is still one global_load_dwordx4, but nothing may assume 16-byte alignment)
+                        typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+                        const f4u t = *reinterpret_cast<const f4u *>(x0 + idx);
+                        v = make_float4(t.x, t.y, t.z, t.w);
                     } else {                                 // clip edge: librosa's centre padding is zeros
                         if (idx >= 0 && idx < g0.n) v.x = x0[idx];
                         if (idx + 1 >= 0 && idx + 1 < g0.n) v.y = x0[idx + 1];

@@ -426,7 +426,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     // Persistent launch: the steps are run chunk by chunk, each run after the chunk's observations are in memory.  Lane 0
     // of the workgroup polls the chunk's flag (agent-scope acquire: the producer ran on other CUs, possibly behind another
     // XCD's L2), sleeping between polls, and publishes the run's last step through LDS; the workgroup barrier behind it
-    // orders every wave's loads after the acquire.  The poll is bounded: a wait that long means the frame stage is not
+    // orders every wave's loads after the acquire.  The poll is bounded (by the pass's size, see aegis_api.hip): a wait that long means the frame stage is not
     // running beside this kernel, and the kernel must end rather than hold its CU.  Everything the wait needs is parked
     // in LDS (the spare doubles behind the wave maxima), so the step loop carries one flag for it, no pointers.
     const bool chunked = __builtin_amdgcn_readfirstlane(p.chunk_flag != nullptr ? 1 : 0) != 0;
@@ -437,6 +437,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         wpar[1] = reinterpret_cast<unsigned long long>(p.chunk_lo);
         wpar[2] = reinterpret_cast<unsigned long long>(p.abort_flag);
         wpar[3] = ((unsigned long long)(unsigned)p.n_chunks << 32) | p.chunk_gen;
+        wpar[4] = p.wait_ticks ? p.wait_ticks : 150000000ull;
         wslot[1] = 0;
     }
     // returns the step the run that starts at step t0 ends before (at most t_stop), or -1
@@ -455,7 +456,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 #pragma nounroll
             while (__hip_atomic_load(flag + k, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != gen) {
                 __builtin_amdgcn_s_sleep(32);
-                if ((++spins & 1023u) == 0 && wall_clock64() - w0 > 150000000ull) {       // 1.5 s
+                if ((++spins & 255u) == 0 && wall_clock64() - w0 > wpar[4]) {            // the launch's bound (aegis_api.hip: 0.1 .. 1.5 s)
                     __hip_atomic_store(reinterpret_cast<uint32_t *>(wpar[2]), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     end = -1;
                     break;

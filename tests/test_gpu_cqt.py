@@ -88,19 +88,41 @@ def test_chroma_cqt_and_similarity(tmp_path):
     h.close()
 
 
+def _tuning_from_one_frame(y, sr=44100, n_fft=2048, bpo=36, start=20480):
+    """What librosa.estimate_tuning must answer for a STATIONARY tone, derived from the peak positions of ONE interior
+    frame and nothing else: Hann-windowed magnitude spectrum, local maxima above a tenth of the largest inside
+    150..4000 Hz, piptrack's parabolic interpolation, the peaks at or above the median magnitude, their residuals in
+    1/bpo-octave bins folded to [-0.5, 0.5), the fullest 0.01-wide histogram bin."""
+    w = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(n_fft) / n_fft)
+    S = np.abs(np.fft.rfft(y[start:start + n_fft].astype(np.float64) * w))
+    fr = np.arange(len(S)) * sr / n_fft
+    k = np.flatnonzero((S[1:-1] > S[:-2]) & (S[1:-1] >= S[2:]) & (S[1:-1] > 0.1 * S.max()) & (fr[1:-1] >= 150) & (fr[1:-1] <= 4000)) + 1
+    avg, den = 0.5 * (S[k + 1] - S[k - 1]), 2 * S[k] - S[k - 1] - S[k + 1]
+    shift = avg / den
+    pitch, mag = (k + shift) * sr / n_fft, S[k] + 0.5 * avg * shift
+    res = np.mod(bpo * np.log2(pitch[mag >= np.median(mag)] / (440.0 / 16)), 1.0)
+    res[res >= 0.5] -= 1.0
+    edges = np.linspace(-0.5, 0.5, 101)
+    return edges[np.argmax(np.histogram(res, edges)[0])], res
+
+
 def test_chroma_follows_the_estimated_tuning():
     """auto_matcher.py:68-69 leaves tuning=None: librosa estimates it and shifts the filter bank.  A clip played
-    20 cents sharp must be analysed with the shifted bank (same chroma as the oracle, different from the nominal grid)."""
+    20 cents flat must be analysed with the shifted bank (same chroma as the oracle, different from the nominal grid).
+    The expected estimate does not come from the code under test: 20 cents flat = -0.6 of a 1/36-octave bin, which
+    folds to +0.4; the parabolic peak interpolation of a 2048-point Hann spectrum is good to a few hundredths of a bin
+    there, and the single-frame derivation above (peak positions only) must give the very bin the estimators return."""
     from oracle import chroma as ochroma
     from spectrogram_midi_amd import similarity
     h = _lib.Handle()
     t = np.arange(3 * 44100) / 44100
-    f = 261.6255653005986 * 2 ** (20 / 1200)
+    f = 261.6255653005986 * 2 ** (-20 / 1200)
     y = sum(a * np.sin(2 * np.pi * k * f * t) for k, a in ((1, 0.4), (2, 0.2), (4, 0.1))).astype(np.float32)
+    expected, residuals = _tuning_from_one_frame(y)
+    assert abs(expected - 0.4) <= 0.05 and np.ptp(residuals) < 0.01          # both kept partials agree: no tie to break
     tn = similarity.estimate_tuning(y, 44100, 36)
+    assert tn == expected
     assert tn == ochroma.estimate_tuning(y, 44100, bins_per_octave=36)
-    assert abs(tn) >= 0.2                                        # 20 cents = 0.6 bin of a third of a semitone; piptrack's
-                                                                 # parabolic peaks of a harmonic tone put it at 0.37
     got = similarity.chroma_cqt(h, [y])[0]
     ref = ochroma.chroma_cqt(y)
     assert np.abs(got - ref).max() < 2e-4
@@ -129,4 +151,24 @@ def test_cqt_configs2_size_properties():
     ref = np.abs(ocqt.cqt(clips[2][:200 * 512], n_bins=84))
     sub = h.cqt([clips[2][:200 * 512]])[0]
     assert np.abs(sub - ref).max() <= 1e-4 * ref.max()
+    h.close()
+
+
+def test_device_entry_equals_the_host_entry():
+    """aegis_cqt_device (PCM and magnitudes resident in HBM) == aegis_cqt, bit for bit, for a ragged batch."""
+    import torch
+    h = _lib.Handle()
+    clips = [signals.polyphonic_clip(2.0, seed=100), signals.guitar_clip(1.3, seed=3), np.zeros(700, np.float32) + 0.1]
+    want = h.cqt(clips)
+    off = np.concatenate([[0], np.cumsum([len(c) for c in clips])]).astype(np.int64)
+    dev = torch.device("cuda", 0)
+    d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    F = [1 + len(c) // 512 for c in clips]
+    d_out = torch.zeros(sum(F) * 84, dtype=torch.float32, device=dev)
+    h.cqt_device(d_pcm.data_ptr(), off, d_out.data_ptr())
+    got = d_out.cpu().numpy()
+    o = 0
+    for Fc, w in zip(F, want):
+        np.testing.assert_array_equal(got[o:o + Fc * 84].reshape(84, Fc), w)
+        o += Fc * 84
     h.close()

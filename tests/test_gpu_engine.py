@@ -460,9 +460,9 @@ def test_balanced_schedule_at_22050_hz(monkeypatch):
 
 
 def test_persistent_viterbi_gives_up(monkeypatch):
-    """The persistent launch's wait is bounded: with one chunk's flag withheld (test hook) the kernel gives up after 1.5 s
-    instead of hanging, the handle falls back to one launch per chunk and repeats the call, and the results are the
-    usual ones."""
+    """The persistent launch's wait is bounded (0.1 s + 0.1 s per million frames of the pass): with one chunk's flag
+    withheld (test hook) the kernel gives up instead of hanging, the handle falls back to one launch per chunk for the
+    next 16 calls and repeats the call, and the results are the usual ones; then the single launch is tried again."""
     clips = _ragged_clips(6, 60)
     monkeypatch.setenv("AEGIS_BALANCED_CHUNK", "64")
     monkeypatch.setenv("AEGIS_TEST_DROP_CHUNK_SIGNAL", "3")
@@ -478,6 +478,15 @@ def test_persistent_viterbi_gives_up(monkeypatch):
         np.testing.assert_array_equal(a[k], b[k])
     a = _analyze_on_device(h, clips)                     # and again on the handle that fell back
     assert int(h.debug_fetch("persistent_fallbacks")[0]) == 1
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k])
+    import time
+    for _ in range(14):                                  # still on the per-chunk schedule
+        _analyze_on_device(h, clips)
+    assert int(h.debug_fetch("persistent_fallbacks")[0]) == 1
+    t0 = time.perf_counter()
+    a = _analyze_on_device(h, clips)                     # the 16th call after the give-up tries the single launch again
+    assert int(h.debug_fetch("persistent_fallbacks")[0]) == 2 and time.perf_counter() - t0 < 1.0      # (the hook still withholds the flag)
     for k in a:
         np.testing.assert_array_equal(a[k], b[k])
     h.close(); ref_h.close()
