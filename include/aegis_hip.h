@@ -67,7 +67,8 @@ typedef struct aegis_config {
                                    AEGIS_PYIN_INIT_UNIFORM (1) = 1/(2B) on every state (SURVEY.md P11's reading, the
                                    behaviour of ABI version 1).  Every Turbo-Mode chunk (aegis_engine.py:197-210) and
                                    every clip starts its own chain, so the choice shows in their first frames. */
-    int64_t max_frames_per_pass; /* workspace bound; 0 -> default (1<<21 frames, ~15 KB each) */
+    int64_t max_frames_per_pass; /* workspace bound; 0 -> as many frames as a third of the free device memory holds
+                                    (~10.3 KB each), between 2^21 and 2^24 */
 } aegis_config;
 
 /* Per-batch outputs, concatenated over clips.  Any pointer may be NULL to skip

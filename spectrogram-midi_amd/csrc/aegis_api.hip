@@ -245,7 +245,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (c.n_mels == 0) c.n_mels = 128;
     if (!(c.fmin > 0)) c.fmin = 82.4068892282175;      // note_to_hz('E2'), aegis_engine.py:63
     if (!(c.fmax > 0)) c.fmax = 1046.5022612023945;    // note_to_hz('C6')
-    if (c.max_frames_per_pass <= 0) c.max_frames_per_pass = (int64_t)1 << 21;
+    const bool auto_pass = c.max_frames_per_pass <= 0;
+    if (auto_pass) c.max_frames_per_pass = (int64_t)1 << 21;
 
     h = new (std::nothrow) aegis_handle();
     if (!h) { g_create_error = "out of host memory"; return AEGIS_ERR_NOMEM; }
@@ -290,6 +291,19 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_RAMP_K")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v <= 64) h->ramp_k = (int)v; }
     if (const char *e = std::getenv("AEGIS_CU_SPLIT")) h->split_limit = std::atoi(e);
     CRTHIP(hipDeviceGetAttribute(&h->n_cus, hipDeviceAttributeMultiprocessorCount, c.device));
+    if (auto_pass) {
+        // Default workspace bound: as many frames per pass as a third of the free device memory holds (a pass needs
+        // ~10.3 KB per frame at the reference's rates, and two workspaces alternate when a call needs several passes), between
+        // 2^21 and 2^24 frames.  On a 288 GB MI355X the 512-clip folder of BASELINE.json configs[3] (8.36 M frames) is then ONE
+        // pass: every clip's Viterbi starts at once and the frame stage of the whole folder runs beside it (411 -> 385 ms).
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            const int64_t per_frame = (int64_t)h->lag_stride * 8 + (int64_t)h->obs_stride * 8 + 8 + 2 * h->tab.n_bins * 2 +
+                                      2 * h->tab.n_bins * 2 / kViterbiChunk + h->tab.n_mels * 4 + 16;
+            const int64_t fit = (int64_t)(free_b / 3) / per_frame;
+            h->max_frames_per_pass = std::min<int64_t>((int64_t)1 << 24, std::max<int64_t>((int64_t)1 << 21, fit));
+        }
+    }
     CRTHIP(hipEventCreateWithFlags(&h->copy_event, hipEventDisableTiming));
     CRTHIP(viterbi_configure());
     CRT(ensure(h, h->vstats, 32));

@@ -23,6 +23,7 @@ def main(fetch_csv, write_csv, n_steps_total, out):
     res = {"units": "KB per bench step (sum over the kernel's launches in one step); rocprofv3 --pmc, separate passes",
            "note": "gfx950: FETCH_SIZE counts 64 B per 128 B request on wide coalesced reads -> double it (MI355X_MICROARCH.md, HBM)",
            "steps_profiled": n_steps_total,
+           "schedule": "AEGIS_VITERBI_PERSISTENT=0: counter collection serialises kernels, so the Viterbi runs one launch per time chunk",
            "per_step": {k: dict(v, launches_per_step=launches[k] / n_steps_total) for k, v in per.items()}}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res, indent=1))
