@@ -256,8 +256,10 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
     // mel: thread t owns chunk t of the filterbank (<= 16 consecutive bins of one triangle) and, for t < n_mels, band t
     const bool has_chunk = want_mel && tid < tb.mel_chunks;
     const int mel_bin = has_chunk ? tb.mel_chunk_bin[tid] : 0;
-    int band_c0 = 0, band_c1 = 0;
-    if (want_mel && tid < p.n_mels) { band_c0 = tb.mel_band_chunk[tid]; band_c1 = tb.mel_band_chunk[tid + 1]; }
+    int band_c0 = 0, band_c1 = 0;             // band (tid mod 128): threads 0..127 sum it for the pair's first frame, 128..255 for the second
+    if (want_mel && (tid & 127) < p.n_mels) { band_c0 = tb.mel_band_chunk[tid & 127]; band_c1 = tb.mel_band_chunk[(tid & 127) + 1]; }
+    float *pw1 = xs;                          // the SECOND frame's power spectrum lives in the frame buffer, dead once that frame's FFT has read it
+    float *part1 = xs + 1040;                 // ... and its chunk sums behind it
     if (tid < 15) pw[1025 + tid] = 0.0f;         // the last chunks read (zero-weighted) bins past 1024
 
     // ---- prologue: running energy of every frame of the workgroup, one frame per lane ------------------------
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         double2 P[2][5];
         int64_t fidx[2] = {0, 0};
         bool flive[2] = {false, false};
+        int fclip[2] = {0, 0};
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
 #pragma unroll
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             const bool live = geo.live;
             const int c = geo.c;
             const int64_t f = geo.f, fo = geo.o;
-            fidx[h] = f; flive[h] = live;
+            fidx[h] = f; flive[h] = live; fclip[h] = c;
 #pragma unroll
             for (int r = 0; r < 8; ++r) xs[tid + r * 256] = nx[r];
             {
@@ -413,12 +416,6 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 p.out_rms[fo] = sqrtf(total / 2048.0f);
             }
             if (!want_fft) continue;
-            // this thread's 16 filterbank weights: requested here, used after the power spectrum is complete
-            float4 w0 = make_float4(0, 0, 0, 0), w1 = w0, w2 = w0, w3 = w0;
-            if (has_chunk) {
-                const float4 *wp = reinterpret_cast<const float4 *>(tb.mel_chunk_w) + tid * 4;
-                w0 = wp[0]; w1 = wp[1]; w2 = wp[2]; w3 = wp[3];
-            }
 
             // ---- A[k] = FFT(x)[k], B[k] = FFT(b)[k] from Z by symmetry; P = A*B; windowed power from A ----------
             auto Aof = [&](int k) {                  // k taken modulo 2048: A[-1] = conj(A[1]), A[1025] = conj(A[1023])
@@ -440,44 +437,62 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                         const float re = (float)(0.5 * A.x - 0.25 * (am.x + ap.x));
                         const float im = (float)(0.5 * A.y - 0.25 * (am.y + ap.y));
                         const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
-                        pw[k] = mag * mag;
+                        (h == 0 ? pw : pw1)[k] = mag * mag;
                     }
                 }
             }
+            if (want_mel && h == 1 && tid < 15) pw1[1025 + tid] = 0.0f;      // the last chunks read (zero-weighted) bins past 1024
             __syncthreads();
             FRM_TICK(3)
-            // ---- mel projection: sparse Slaney triangles.  Every <= 16-bin chunk of a triangle is one thread's float32
-            // fma chain; a band then adds its chunks' sums in order (the widest band has six).  Clip maximum.
+        }
+        // ---- mel projection of BOTH frames of the pair: sparse Slaney triangles.  Every <= 16-bin chunk of a triangle is
+        // one thread's float32 fma chain per frame (the 16 weights requested once per pair); a band then adds its
+        // chunks' sums in order (the widest band has six), threads 0..127 for the first frame and 128..255 for the
+        // second.  Clip maximum.  One section per pair instead of one per frame: half the barriers, half the weight
+        // traffic, all four waves busy in the band phase.
+        if (want_mel) {
             if (has_chunk) {
-                const float *pp = pw + mel_bin;
-                float acc = 0.0f;
-                acc = fmaf(w0.x, pp[0], acc); acc = fmaf(w0.y, pp[1], acc); acc = fmaf(w0.z, pp[2], acc); acc = fmaf(w0.w, pp[3], acc);
-                acc = fmaf(w1.x, pp[4], acc); acc = fmaf(w1.y, pp[5], acc); acc = fmaf(w1.z, pp[6], acc); acc = fmaf(w1.w, pp[7], acc);
-                acc = fmaf(w2.x, pp[8], acc); acc = fmaf(w2.y, pp[9], acc); acc = fmaf(w2.z, pp[10], acc); acc = fmaf(w2.w, pp[11], acc);
-                acc = fmaf(w3.x, pp[12], acc); acc = fmaf(w3.y, pp[13], acc); acc = fmaf(w3.z, pp[14], acc); acc = fmaf(w3.w, pp[15], acc);
-                part[tid] = acc;
+                const float4 *wp = reinterpret_cast<const float4 *>(tb.mel_chunk_w) + tid * 4;
+                const float4 w0 = wp[0], w1 = wp[1], w2 = wp[2], w3 = wp[3];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float *pp = (h == 0 ? pw : pw1) + mel_bin;
+                    float acc = 0.0f;
+                    acc = fmaf(w0.x, pp[0], acc); acc = fmaf(w0.y, pp[1], acc); acc = fmaf(w0.z, pp[2], acc); acc = fmaf(w0.w, pp[3], acc);
+                    acc = fmaf(w1.x, pp[4], acc); acc = fmaf(w1.y, pp[5], acc); acc = fmaf(w1.z, pp[6], acc); acc = fmaf(w1.w, pp[7], acc);
+                    acc = fmaf(w2.x, pp[8], acc); acc = fmaf(w2.y, pp[9], acc); acc = fmaf(w2.z, pp[10], acc); acc = fmaf(w2.w, pp[11], acc);
+                    acc = fmaf(w3.x, pp[12], acc); acc = fmaf(w3.y, pp[13], acc); acc = fmaf(w3.z, pp[14], acc); acc = fmaf(w3.w, pp[15], acc);
+                    (h == 0 ? part : part1)[tid] = acc;
+                }
             }
-            if (want_mel) __syncthreads();
-            if (want_mel && wid < 2) {
+            __syncthreads();
+            {
+                const int h = wid >> 1, bt = tid & 127;           // waves 0, 1: first frame; waves 2, 3: second
+                const bool live = flive[h];
+                const float *pt = h == 0 ? part : part1;
                 float acc = 0.0f;
-                if (tid < p.n_mels && live) {
+                if (bt < p.n_mels && live) {
                     // the band's chunk sums added in order; the first six (every band of the default bank has at most
                     // six) are requested together instead of one LDS round trip per chunk
+                    const int c0 = band_c0, c1 = band_c1;
                     float pv[6];
 #pragma unroll
-                    for (int k = 0; k < 6; ++k) pv[k] = part[min(band_c0 + k, 255)];
-                    acc = band_c0 < band_c1 ? pv[0] : 0.0f;
+                    for (int k = 0; k < 6; ++k) pv[k] = pt[min(c0 + k, 255)];
+                    acc = c0 < c1 ? pv[0] : 0.0f;
 #pragma unroll
-                    for (int k = 1; k < 6; ++k) if (band_c0 + k < band_c1) acc = acc + pv[k];
-                    for (int cidx = band_c0 + 6; cidx < band_c1; ++cidx) acc = acc + part[cidx];
-                    p.melpow[f * p.n_mels + tid] = acc;
+                    for (int k = 1; k < 6; ++k) if (c0 + k < c1) acc = acc + pv[k];
+                    for (int cidx = c0 + 6; cidx < c1; ++cidx) acc = acc + pt[cidx];
+                    p.melpow[fidx[h] * p.n_mels + bt] = acc;
                 }
                 // powers are >= 0: float order == unsigned order of the bits
                 const unsigned m = wave_umax(__float_as_uint(acc));
-                if (lane == 0 && live) atomicMax(&p.clipmax[c], m);
+                if (lane == 0 && live) atomicMax(&p.clipmax[fclip[h]], m);
             }
-            FRM_TICK(4)
+            // pw, pw1 and the chunk sums are next written behind the barriers of the inverse FFT; without it the next pair's
+            // first frame would land in the frame buffer while the second frame's chunk sums are still being read
+            if (!want_pyin) __syncthreads();
         }
+        FRM_TICK(4)
         if (!want_pyin) continue;
 
         // ---- one inverse FFT for both frames: conj(Q), Q = Hermitian extension of P0 + i*P1 ---------------------

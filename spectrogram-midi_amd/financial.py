@@ -111,13 +111,21 @@ class FinancialPitchAnalyzer:
 
     @staticmethod
     def _ghost_density(note_events):
-        max_time = max(e["end"] for e in note_events)
-        density = np.zeros(len(np.linspace(0, max_time, int(max_time * 10))))
-        for e in note_events:
-            a, b = int(e["start"] * 10), int(e["end"] * 10)
-            if a < len(density):
-                density[a:min(b, len(density))] += 1
-        return density
+        """The note-density track of filter_ghost_notes_rsi (financial_analysis.py:333-347): +1 over [start*10, end*10) per
+        note.  Counts are small integers, so the difference-array form below gives the same float64 values as the
+        reference's slice increments."""
+        starts = np.fromiter((e["start"] for e in note_events), dtype=np.float64, count=len(note_events))
+        ends = np.fromiter((e["end"] for e in note_events), dtype=np.float64, count=len(note_events))
+        max_time = ends.max()
+        n = int(max_time * 10)                               # len(np.linspace(0, max_time, int(max_time * 10)))
+        a, b = (starts * 10).astype(np.int64), (ends * 10).astype(np.int64)
+        ok = a < n
+        b = np.minimum(b, n)
+        ok &= b > a
+        diff = np.zeros(n + 1)
+        np.add.at(diff, a[ok], 1.0)
+        np.add.at(diff, b[ok], -1.0)
+        return np.cumsum(diff[:-1]) if n > 0 else np.zeros(0)
 
     @staticmethod
     def _ghost_keep(note_events, rsi_values, rsi_threshold):

@@ -295,3 +295,14 @@ def test_representative_interior_rows_decode_like_the_true_matrix(host_handle):
         a = opyin.viterbi_states(lp, LT_true, log_p_init)
         b = opyin.viterbi_states(lp, LT_rep, log_p_init)
         np.testing.assert_array_equal(a, b)
+
+
+def test_graft_entry_imports_resolve():
+    """Everything __graft_entry__.smoke() imports exists where it says (the GPU suite runs smoke() itself)."""
+    import ast
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for node in ast.walk(ast.parse(src)):
+        if isinstance(node, ast.ImportFrom) and node.module and node.level == 0:
+            mod = __import__(node.module, fromlist=[a.name for a in node.names])
+            for a in node.names:
+                assert hasattr(mod, a.name), (node.module, a.name)

@@ -490,3 +490,9 @@ def test_persistent_viterbi_gives_up(monkeypatch):
     for k in a:
         np.testing.assert_array_equal(a[k], b[k])
     h.close(); ref_h.close()
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke() hook itself: one small analyze on cuda:0 checked against the oracle."""
+    import __graft_entry__ as g
+    g.smoke()

@@ -14,6 +14,8 @@ run() {
 import json
 l=[x for x in open("$O/bench_$n.log") if x.startswith("{")][-1]; d=json.loads(l)
 print("$n", d["ms_per_step"], d["value"], d["roofline"]["kernel_ms"], d.get("viterbi_list_only_rate"))
+if d.get("persistent_fallbacks", 0):      # the single Viterbi launch gave up waiting: the line above is the slower schedule
+    print("WARNING: $n persistent_fallbacks =", d["persistent_fallbacks"]); raise SystemExit(3)
 PY
 }
 EXTRA_ENV=("$@"); [ ${#EXTRA_ENV[@]} -eq 0 ] && EXTRA_ENV=(AEGIS_X=0)
