@@ -9,6 +9,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <mutex>
 #include <new>
@@ -68,7 +69,7 @@ struct aegis_handle {
     // workspaces (grow-only): passes alternate between the two, so that the frame stage of one pass runs under the
     // Viterbi of the previous one
     struct Work {
-        DevBuf dfn, yin, logobs, logunv, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
+        DevBuf dfn, yin, logobs, logunv, obs_seg, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
         DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate, chunk_lo, chunk_flag;
     } work[2];
     int last_work = 0;
@@ -112,7 +113,7 @@ struct aegis_stream {
     int64_t n_samples = 0;      // samples received
     int64_t frames_done = 0;    // frames analysed (= Viterbi columns produced)
     bool closed = false;
-    DevBuf pcm, dfn, logobs, logunv, ptr, cmap, bnd, states, live, melpow, clipmax, rake_raw, vstate, meta;
+    DevBuf pcm, dfn, logobs, logunv, obs_seg, ptr, cmap, bnd, states, live, melpow, clipmax, rake_raw, vstate, meta;
     DevBuf o_f0, o_voiced, o_vprob, o_rms, o_rake, o_sdb;
     std::vector<int64_t> host_meta;
     // captured hipGraph of one fixed-size push (built lazily for the first push size that is a multiple of hop)
@@ -370,7 +371,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
     for (auto &w : h->work)
-        for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
+        for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.obs_seg, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
                           &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
                           &w.vstate, &w.chunk_lo, &w.chunk_flag})
             free_buf(*b);
@@ -699,7 +700,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         ENS(order, nc * 4); ENS(chunk_off, (nc + 1) * 8); ENS(sel_off, (size_t)nk * (nc + 1) * 8);
         if (py) {
             ENS(dfn, fp * h->lag_stride * 8); if (h->debug_stages) ENS(yin, fp * h->yin_stride * 8);
-            ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8);
+            ENS(logobs, fp * h->obs_stride * 8); ENS(logunv, fp * 8); ENS(obs_seg, fp * 4);
             ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
             ENS(states, fp * 4); ENS(vstate, (size_t)nc * S * 8);
             ENS(chunk_lo, (size_t)nk * 8); ENS(chunk_flag, (size_t)nk * 4);
@@ -746,6 +747,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.yin = (py && h->debug_stages) ? static_cast<double *>(w.yin.p) : nullptr; p.yin_stride = h->yin_stride;
         p.logobs = static_cast<double *>(w.logobs.p); p.obs_stride = h->obs_stride;
         p.logunv = static_cast<double *>(w.logunv.p);
+        p.obs_seg = static_cast<int32_t *>(w.obs_seg.p);
         p.ptr = static_cast<uint16_t *>(w.ptr.p);
         p.cmap = static_cast<uint16_t *>(w.cmap.p);
         p.chunk_off = static_cast<int64_t *>(w.chunk_off.p);
@@ -1074,6 +1076,7 @@ static PassParams stream_params(aegis_stream *st, const int64_t *dm) {
     p.yin = nullptr; p.yin_stride = h->yin_stride;
     p.logobs = static_cast<double *>(st->logobs.p); p.obs_stride = h->obs_stride;
     p.logunv = static_cast<double *>(st->logunv.p);
+    p.obs_seg = static_cast<int32_t *>(st->obs_seg.p);
     p.ptr = static_cast<uint16_t *>(st->ptr.p); p.cmap = static_cast<uint16_t *>(st->cmap.p);
     p.bnd = static_cast<int32_t *>(st->bnd.p); p.states = static_cast<int32_t *>(st->states.p);
     p.live_states = static_cast<int32_t *>(st->live.p);
@@ -1158,7 +1161,7 @@ static void stream_release(aegis_stream *st) noexcept {
     if (st->graph) (void)hipGraphDestroy(st->graph);
     if (st->pin_samples) (void)hipHostFree(st->pin_samples);
     if (st->pin_result) (void)hipHostFree(st->pin_result);
-    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->dfn, &st->logobs, &st->logunv, &st->ptr, &st->cmap, &st->bnd, &st->states,
+    for (DevBuf *b : {&st->ctl, &st->g_staging, &st->g_result, &st->pcm, &st->dfn, &st->logobs, &st->logunv, &st->obs_seg, &st->ptr, &st->cmap, &st->bnd, &st->states,
                       &st->live, &st->melpow, &st->clipmax, &st->rake_raw, &st->vstate, &st->meta, &st->o_f0, &st->o_voiced,
                       &st->o_vprob, &st->o_rms, &st->o_rake, &st->o_sdb})
         free_buf(*b);
@@ -1176,7 +1179,7 @@ static int stream_open_locked(aegis_handle *h, int64_t max_samples, aegis_stream
     int rc = AEGIS_OK;
     auto need = [&](DevBuf &b, size_t bytes) { if (rc == AEGIS_OK) rc = ensure(h, b, bytes); };
     need(st->pcm, max_samples * 4); need(st->dfn, F * h->lag_stride * 8);
-    need(st->logobs, F * h->obs_stride * 8); need(st->logunv, F * 8); need(st->ptr, F * S * 2);
+    need(st->logobs, F * h->obs_stride * 8); need(st->logunv, F * 8); need(st->obs_seg, F * 4); need(st->ptr, F * S * 2);
     need(st->cmap, nch * S * 2); need(st->bnd, nch * 4); need(st->states, F * 4); need(st->live, F * 4);
     need(st->melpow, F * t.n_mels * 4); need(st->clipmax, 16); need(st->rake_raw, F); need(st->vstate, S * 8);
     need(st->meta, 9 * 8); need(st->ctl, sizeof(StreamCtl)); need(st->g_staging, 8192 * 4); need(st->g_result, 256);
@@ -1636,7 +1639,24 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     const aegis_handle::Work &lw = h->work[h->last_work];      // rows in the order the last pass took its clips: longest first
     if (n == "dfn") { src = lw.dfn.p; count = F * h->lag_stride; }
     else if (n == "yin") { src = lw.yin.p; count = F * h->yin_stride; }
-    else if (n == "logobs") { src = lw.logobs.p; count = F * h->obs_stride; }
+    else if (n == "logobs") {            // dense rows: the segments the kernel did not store (obs_seg) are all log(tiny)
+        count = F * h->obs_stride;
+        if (h->device < 0 || !lw.logobs.p || !lw.obs_seg.p) { h->err = "stage was not run"; return AEGIS_ERR_INVALID; }
+        if (dst && cap > 0) {
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipStreamSynchronize(h->stream));
+            std::vector<double> rows((size_t)count);
+            std::vector<int32_t> seg((size_t)F);
+            HIPCHK(h, hipMemcpy(rows.data(), lw.logobs.p, (size_t)count * 8, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(seg.data(), lw.obs_seg.p, (size_t)F * 4, hipMemcpyDeviceToHost));
+            const double log_tiny = h->tab.log_tiny;
+            for (int64_t f = 0; f < F; ++f)
+                for (int b = 0; b < h->obs_stride; ++b)
+                    if (!(seg[(size_t)f] & (0x40000000 | (1 << (b >> 6))))) rows[(size_t)(f * h->obs_stride + b)] = log_tiny;
+            std::memcpy(dst, rows.data(), (size_t)std::min(count, cap) * 8);
+        }
+        return count;
+    }
     else if (n == "logunv") { src = lw.logunv.p; count = F; }
     else if (n == "states") { src = lw.states.p; count = F; esz = 4; }
     else if (n == "melpow") { src = lw.melpow.p; count = F * h->tab.n_mels; esz = 4; }

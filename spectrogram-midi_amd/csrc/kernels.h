@@ -85,6 +85,9 @@ struct PassParams {
     double *yin;   int32_t yin_stride;   // optional [F][yin_stride]: CMND for lags min..max, written only for the stage tests
     double *logobs; int32_t obs_stride;  // [F][obs_stride]   log(obs+tiny), voiced bins
     double *logunv;                      // [F]               log(unvoiced obs+tiny)
+    int32_t *obs_seg;                    // [F]  which 64-bin segments of the logobs row are written: bit s = some bin of [64 s, 64 s + 64)
+                                         //      is observed; bit 30 = hard frame (unvoiced observation log(tiny)), the whole row is written.
+                                         //      Any other segment is all log(tiny), is never stored and must not be read.
     uint16_t *ptr;                       // [F][2*n_bins]     Viterbi back-pointers
     uint16_t *cmap;                      // [chunks][2*n_bins] composed chunk maps
     int64_t *chunk_off;                  // [n_clips+1]       first chunk of each clip

@@ -735,6 +735,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
 
     OBS_TICK(3)
     double vp = 0.0;
+    unsigned segm = 0;               // 64-bin segments of the observation row with an observed bin (wave-uniform)
     const int rounds = (K + 63) >> 6;
     // Everything below is unrolled over the rounds of 64 troughs a frame may need (up to 8); nearly every frame has at
     // most 128 troughs, so the body exists twice: the two-round instance is what runs (a quarter of the code: the three
@@ -869,6 +870,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
             // probability has the same bin.  Bin == B falls in the unvoiced half and is dropped.
             bool winq[MAXR];
             double prq[MAXR];
+            unsigned lseg = 0;           // segments of the row this lane's winners fall in
             // the next trough that carries probability, for every trough at once: one ballot per round of 64 troughs and a
             // per-lane shift instead of a walk over tbin (a data-dependent loop of dependent LDS reads per lane)
             int binq[MAXR];
@@ -893,7 +895,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                             if (hasm[q2]) k2 = q2 * 64 + (int)__ffsll((long long)hasm[q2]) - 1;
                     }
                     const bool win = (k2 < 0) || ((int)tbin[k2 < 0 ? 0 : k2] != bin);
-                    if (win) { prq[q] = tp[q * 64 + lane]; row[bin] = log(prq[q] + DBL_MIN); }
+                    if (win) { prq[q] = tp[q * 64 + lane]; row[bin] = log(prq[q] + DBL_MIN); lseg |= 1u << (bin >> 6); }
                     winq[q] = win;
                 }
             }
@@ -915,16 +917,24 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                 }
             }
             vp = s < 0.0 ? 0.0 : (s > 1.0 ? 1.0 : s);
+            for (int sg = 0; sg * 64 < B; ++sg)
+                if (__ballot((lseg >> sg) & 1u)) segm |= 1u << sg;
         }
     };
     if (rounds <= 2) tail(std::integral_constant<int, 2>{});
     else tail(std::integral_constant<int, kMaxRounds>{});
     wave_sync();
     OBS_TICK(7)
+    // Only the 64-bin segments that hold an observed bin are stored (the Viterbi kernel skips a voiced wave whose segment
+    // is all log(tiny) at an easy frame and never loads it); at a hard frame -- unvoiced observation log(tiny) -- every
+    // value matters and the whole row goes out.
+    const double unv = (1.0 - vp) / (double)B;
+    if (unv == 0.0) segm = 0x40000000u | ((1u << ((B + 63) >> 6)) - 1u);
     double *__restrict__ orow = p.logobs + f * (int64_t)p.obs_stride;
-    for (int b = lane; b < B; b += 64) orow[b] = row[b];
+    for (int b = lane, sg = 0; b < B; b += 64, ++sg)
+        if ((segm >> sg) & 1u) orow[b] = row[b];
     if (lane == 0) {
-        const double unv = (1.0 - vp) / (double)B;
+        p.obs_seg[f] = (int32_t)segm;
         p.logunv[f] = log(unv + DBL_MIN);
         if (p.out_vprob != nullptr) p.out_vprob[fo] = vp;
     }

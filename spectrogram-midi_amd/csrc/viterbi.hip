@@ -58,6 +58,12 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     const int os = p.obs_stride;
     const double *__restrict__ lobs = p.logobs + f0 * os;
     const double *__restrict__ lunv = p.logunv + f0;
+    const int32_t *__restrict__ oseg = p.obs_seg + f0;
+    // voiced observation of bin b at frame t: only the row segments obs_seg names are stored, the rest are log(tiny)
+    auto voiced_obs = [&](int t, int b) {
+        const int sg = oseg[t];
+        return (sg & (0x40000000 | (1 << (b >> 6)))) ? lobs[(int64_t)t * os + b] : p.log_tiny;
+    };
     uint16_t *__restrict__ ptr = p.ptr + f0 * S;
     const int64_t ch0 = p.chunk_off[c];
     uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
@@ -81,7 +87,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     double myv = -INFINITY;
     if (act) {
         if (vt_begin == 0) {
-            const double lp = v2 ? lunv[0] : lobs[b2];
+            const double lp = v2 ? lunv[0] : voiced_obs(0, b2);
             myv = lp + (v2 ? p.log_pinit_u : p.log_pinit_v);
         } else {
             myv = vst[j];
@@ -114,7 +120,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     double *cur = val, *nxt = val + SP;
     for (int t = t_lo; t < t_hi; ++t) {
         double lp = 0.0;
-        if (act) lp = v2 ? lunv[t] : lobs[(int64_t)t * os + b2];
+        if (act) lp = v2 ? lunv[t] : voiced_obs(t, b2);
         double best = -INFINITY;
         int bi = 0;
         if (act) {
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int os = p.obs_stride;
     const double *__restrict__ lobs = p.logobs + f0 * os;
     const double *__restrict__ lunv = p.logunv + f0;
+    const int32_t *__restrict__ oseg = p.obs_seg + f0;
     uint16_t *__restrict__ ptr = p.ptr + f0 * S;
     const int64_t ch0 = p.chunk_off[c];
     uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
@@ -486,7 +493,8 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     bool observed = false;        // voiced state whose observation at the column's frame is not log(tiny)
     if (act) {
         const int tprev = vt_begin == 0 ? 0 : t_lo - 1;
-        const double lp = vp ? lunv[tprev] : lobs[(int64_t)tprev * os + b2c];
+        const double lp = vp ? lunv[tprev]
+                             : ((oseg[tprev] & (0x40000000 | (1 << (wlo >> 6)))) ? lobs[(int64_t)tprev * os + b2c] : p.log_tiny);
         myv = vt_begin == 0 ? lp + (vp ? p.log_pinit_u : p.log_pinit_v) : vst[j];
         observed = !vp && lp != p.log_tiny;
         store_value(0, myv);
@@ -595,16 +603,23 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     }
     // Observations are requested ONE STEP AHEAD (never past the run: the next time chunk's rows may not be written yet):
     // a step starts by deciding, from its own observations, whether this wave has anything to compute.
-    double lp_n = lp_base[(int64_t)t * lp_stride];
-    double lu_n = lunv[t];
+    // A voiced wave loads its 64-bin segment of the row only where obs_seg says it was stored (its bit, or the hard-frame
+    // bit); otherwise the load is pointed at the frame's unvoiced observation -- a line the unvoiced waves fetch anyway --
+    // and the step is skipped below, so the value is never looked at.  No branch: one select on the address.
+    const int seg_bits = vp ? 0 : (0x40000000 | (1 << (wlo >> 6)));           // unvoiced waves: need = vp = 1 at every step
+    int need_n = (__builtin_amdgcn_readfirstlane(oseg[t]) & seg_bits) | vp;
+    double lp_n = (need_n ? lp_base + (int64_t)t * lp_stride : lunv + t)[0];
+    int sg_n = oseg[min(t + 1, t_end - 1)];       // the segment word runs two steps ahead: it addresses the next step's load
     for (; t < t_end; ++t) {
         VIT_TICK(5)
         // every lane loads (lanes without a state read bin 0): the sum below then needs no wait at a control-flow join
-        const double lp = lp_n, lu = lu_n;
+        const double lp = lp_n;
+        const int need = need_n;
         {
             const int tn = min(t + 1, t_end - 1);
-            lp_n = lp_base[(int64_t)tn * lp_stride];
-            lu_n = lunv[tn];
+            need_n = (__builtin_amdgcn_readfirstlane(sg_n) & seg_bits) | vp;
+            lp_n = (need_n ? lp_base + (int64_t)tn * lp_stride : lunv + tn)[0];
+            sg_n = oseg[min(t + 2, t_end - 1)];
         }
         const int cur = __builtin_amdgcn_readfirstlane(ph);
         // Dead voiced targets.  Call a voiced state dead at frame t when its observation is log(tiny), and frame t easy
@@ -617,10 +632,9 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         // wave ALL of whose targets are dead at an easy frame (59 % of the voiced wave-steps on the bench clips) does
         // exactly that and goes straight to the end-of-step barrier.
         // (an easy frame's unvoiced observation is log((1 - voiced_prob) / B + tiny) >= log(2^-53 / B) = -42.8, a hard
-        // frame's is log(tiny) = -708.4: the high word of -100.0 separates them)
-        // (negative doubles: the larger magnitude has the larger high word, as signed integers too)
-        const bool skip = !vp && __builtin_amdgcn_readfirstlane(__double2hiint(lu)) < __double2hiint(-100.0) &&
-                          __ballot(act && lp != p.log_tiny) == 0ull;
+        // frame's is log(tiny) = -708.4.)  The observation kernel has made the decision already: obs_seg carries one bit
+        // per 64-bin segment with an observed bin and the hard-frame bit, and a segment without either was not even stored.
+        const bool skip = !need;
         const double *colr = val + cur * PB;        // the column being read
         // observed bins within reach of this wave's targets, [wlo - H, whi + H], span <= 3 mask words: the masks and
         // this lane's share of those words' values (bin 64 w + lane, voiced) are fetched here, far ahead of the list
@@ -885,7 +899,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
         }
         const double sum = lp + best;
         myv = (act && !skip) ? sum : -INFINITY;
-        observed = act && !vp && lp != p.log_tiny;
+        observed = act && !vp && !skip && lp != p.log_tiny;       // a skipped step did not load the row at all
         n_skip += skip ? 1 : 0;
         if (skip) {
             if (act) store_value(cur ^ 1, -INFINITY);
