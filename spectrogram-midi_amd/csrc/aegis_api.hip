@@ -176,6 +176,13 @@ PassParams base_params(const Tables &t) {
     return p;
 }
 
+// The frame kernel's epilogue forms the CMND unless the stage tests want the difference function and the CMND as separate
+// buffers (AEGIS_DEBUG_STAGES=1), the experiment knob AEGIS_CMND_IN_FRAME=0 is set, or the lag range does not fit its LDS.
+int cmnd_in_frame(const aegis_handle *h) {
+    static const bool off = [] { const char *e = std::getenv("AEGIS_CMND_IN_FRAME"); return e && e[0] == '0'; }();
+    return (!off && !h->debug_stages && frame_cmnd_supported(h->tab.max_period)) ? 1 : 0;
+}
+
 void free_buf(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr; b.cap = 0;
@@ -745,6 +752,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.n_clips = nc; p.n_frames = fp;
         p.dfn = static_cast<double *>(w.dfn.p); p.lag_stride = h->lag_stride;
         p.yin = (py && h->debug_stages) ? static_cast<double *>(w.yin.p) : nullptr; p.yin_stride = h->yin_stride;
+        p.cmnd_in_frame = cmnd_in_frame(h);
         p.logobs = static_cast<double *>(w.logobs.p); p.obs_stride = h->obs_stride;
         p.logunv = static_cast<double *>(w.logunv.p);
         p.obs_seg = static_cast<int32_t *>(w.obs_seg.p);
@@ -1074,6 +1082,7 @@ static PassParams stream_params(aegis_stream *st, const int64_t *dm) {
     p.n_clips = 1;
     p.dfn = static_cast<double *>(st->dfn.p); p.lag_stride = h->lag_stride;
     p.yin = nullptr; p.yin_stride = h->yin_stride;
+    p.cmnd_in_frame = cmnd_in_frame(h);
     p.logobs = static_cast<double *>(st->logobs.p); p.obs_stride = h->obs_stride;
     p.logunv = static_cast<double *>(st->logunv.p);
     p.obs_seg = static_cast<int32_t *>(st->obs_seg.p);

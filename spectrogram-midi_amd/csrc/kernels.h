@@ -81,7 +81,10 @@ struct PassParams {
     uint32_t *abort_flag;
     uint64_t wait_ticks;         // bound of one chunk wait in 100 MHz wall-clock ticks (0: 1.5 s)
     // workspace (strides in elements)
-    double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period
+    double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period; with
+                                         //                   cmnd_in_frame the entries tau >= min_period hold the CMND instead
+    int32_t cmnd_in_frame;               // the frame kernel's epilogue forms the CMND (cumsum walk of all its frames at once);
+                                         // 0: pyin_obs_kernel walks it frame by frame (stage tests, lag ranges the epilogue cannot hold)
     double *yin;   int32_t yin_stride;   // optional [F][yin_stride]: CMND for lags min..max, written only for the stage tests
     double *logobs; int32_t obs_stride;  // [F][obs_stride]   log(obs+tiny), voiced bins
     double *logunv;                      // [F]               log(unvoiced obs+tiny)
@@ -109,6 +112,7 @@ struct PassParams {
 constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
 
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s);
+bool frame_cmnd_supported(int max_period);   // the frame kernel's LDS holds the CMND rows of a workgroup's frames (PassParams::cmnd_in_frame)
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
 bool viterbi_band_applies(const PassParams &p, const DevTables &t);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry

@@ -185,6 +185,41 @@ __device__ __forceinline__ void energy_walk(Fetch fetch, float *__restrict__ row
 #undef AEGIS_CHAIN4
 #undef AEGIS_SQ
 }
+// doubles per CMND row of the frame kernel's epilogue: lags 0..max_period, even, half of it odd, so that the 16-byte
+// accesses of 16 lanes (one row each) fall on 16 distinct bank groups
+__host__ __device__ inline int frame_cmnd_stride(int max_period) {
+    int s = (max_period + 2) & ~1;
+    if (((s >> 1) & 1) == 0) s += 2;
+    return s;
+}
+// One lane's walk of np.cumsum(d[1:]) (float64, strictly sequential) over its LDS row, IN PLACE: r[tau] becomes
+// cs[tau] = d[1] + ... + d[tau].  Straight-line groups of 8 lags over two register sets, a group's 16-byte reads requested
+// while the group before it is chained; the look-ahead may read up to 64 bytes past the row (the next row, or the slack
+// behind the last one), never writes there.
+__device__ __forceinline__ void cmnd_walk(double *__restrict__ r, int mp) {
+    constexpr int GL = 8;
+    double cs = r[1];
+    double2 ra[GL / 2], rb[GL / 2];
+    auto request = [&](double2 (&q)[GL / 2], int t0) {
+#pragma unroll
+        for (int i = 0; i < GL / 2; ++i) q[i] = *reinterpret_cast<const double2 *>(r + t0 + 2 * i);
+    };
+    auto group = [&](double2 (&cur)[GL / 2], double2 (&nxt)[GL / 2], int t0) {
+        request(nxt, t0 + GL);
+#pragma unroll
+        for (int i = 0; i < GL / 2; ++i) {
+            double2 o;
+            cs = cs + cur[i].x; o.x = cs;
+            cs = cs + cur[i].y; o.y = cs;
+            *reinterpret_cast<double2 *>(r + t0 + 2 * i) = o;
+        }
+    };
+    int tau = 2;
+    request(ra, tau);
+    for (; tau + 2 * GL - 1 <= mp; tau += 2 * GL) { group(ra, rb, tau); group(rb, ra, tau + GL); }
+    if (tau + GL - 1 <= mp) { group(ra, rb, tau); tau += GL; }
+    for (; tau <= mp; ++tau) { cs = cs + r[tau]; r[tau] = cs; }
+}
 constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1040 * 4 + 128 * 4 + 16 * 4 + 256 * 4;
 
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
@@ -205,6 +240,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
     float *blk = red + 128;                                      // [16]
     float *part = blk + 16;                                      // [256]  mel partial sums, one per 16-bin chunk of a triangle
     float *en = part + 256;                                      // [frames_per_wg][en_stride] running energies
+    int64_t *frow = reinterpret_cast<int64_t *>(en + (size_t)frames_per_wg * en_stride);   // [frames_per_wg] workspace row of each frame, -1: not live (epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
     const int64_t n_sel = geo_n_sel(p);
@@ -354,6 +390,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             const int c = geo.c;
             const int64_t f = geo.f, fo = geo.o;
             fidx[h] = f; flive[h] = live; fclip[h] = c;
+            if (tid == 0) frow[pr + h] = live ? f : -1;
 #pragma unroll
             for (int r = 0; r < 8; ++r) xs[tid + r * 256] = nx[r];
             {
@@ -545,8 +582,59 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         // the next pair's first write into z (pass 1) comes after that frame's first barrier
         FRM_TICK(6)
     }
+    // ---- epilogue: cumulative-mean-normalised difference of ALL the workgroup's frames -------------------------------
+    // yin[tau] = d[tau] / (cumsum(d[1:])[tau] / tau + tiny), pitch.py::_cumulative_mean_normalized_difference.  np.cumsum is
+    // strictly sequential in float64: one lane per frame walks it, all frames of the workgroup in one wave's lanes at once
+    // (pyin_obs_kernel spent a third of its time issuing whole-wave instructions for one lane's walk, frame after frame).
+    // Every LDS buffer is dead by now and together they hold the frames' rows; the d rows come back from L2 (this workgroup
+    // wrote them a moment ago) into registers and LDS, the walk turns the LDS copy into the cumsum in place, the quotients
+    // run on all threads from the register copy and go out over d[min_period..]: pyin_obs_kernel reads the CMND directly.
+    if (want_pyin && p.cmnd_in_frame) {
+        const int RS = frame_cmnd_stride(mp), minp = p.min_period;
+        double *rows = reinterpret_cast<double *>(fsm);
+        __syncthreads();                         // the d rows are written (workgroup-scope release), LDS is free
+        double dv[kFramesPerWg][3];
+        int64_t fr[kFramesPerWg];
+#pragma unroll
+        for (int i = 0; i < kFramesPerWg; ++i) fr[i] = i < nfr ? frow[i] : -1;
+        __syncthreads();                         // frow sits behind the running energies: read before the rows may cover it
+#pragma unroll
+        for (int i = 0; i < kFramesPerWg; ++i) {
+            const double *__restrict__ drow = p.dfn + (fr[i] < 0 ? 0 : fr[i]) * (int64_t)p.lag_stride;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int tau = tid + 256 * u;
+                dv[i][u] = (fr[i] >= 0 && tau <= mp) ? drow[tau] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < kFramesPerWg; ++i) {
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int tau = tid + 256 * u;
+                if (i < nfr && tau <= mp) rows[i * RS + tau] = dv[i][u];
+            }
+        }
+        __syncthreads();
+        FRM_TICK(7)
+        if (wid == 0) __builtin_amdgcn_s_setprio(3);
+        if (wid == 0 && lane < nfr) cmnd_walk(rows + lane * RS, mp);
+        if (wid == 0) __builtin_amdgcn_s_setprio(0);
+        __syncthreads();
+        FRM_TICK(8)
+#pragma unroll
+        for (int i = 0; i < kFramesPerWg; ++i) {
+            double *__restrict__ drow = p.dfn + (fr[i] < 0 ? 0 : fr[i]) * (int64_t)p.lag_stride;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int tau = tid + 256 * u;
+                if (fr[i] >= 0 && tau >= minp && tau <= mp) drow[tau] = dv[i][u] / (rows[i * RS + tau] / (double)tau + DBL_MIN);
+            }
+        }
+        FRM_TICK(9)
+    }
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-    if (blockIdx.x == 1000 && (tid == 0 || tid == 64)) { for (int k = 0; k < 7; ++k) g_frm_dbg[(tid ? 8 : 0) + k] = facc[k]; }
+    if (blockIdx.x == 1000 && (tid == 0 || tid == 64)) { for (int k = 0; k < 7; ++k) g_frm_dbg[(tid ? 8 : 0) + k] = facc[k]; if (tid == 0) { g_frm_dbg[7] = facc[7] + facc[8] + facc[9]; } }
 #endif
 }
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
@@ -651,6 +739,18 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     const int mp = p.max_period, minp = p.min_period;
     const double *__restrict__ dr = p.dfn + f * (int64_t)p.lag_stride;
     wave_sync();                            // the previous frame's output row has been read out of this wave's buffers
+    if (p.cmnd_in_frame) {
+        // the frame kernel's epilogue has formed the CMND already (dfn[min_period..max_period] holds it): load and go on
+        for (int base = lane; base < nl; base += 320) {
+            double t5[5];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) t5[u] = dr[minp + min(base + 64 * u, nl - 1)];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) if (base + 64 * u < nl) y[base + 64 * u] = t5[u];
+        }
+        wave_sync();
+        OBS_TICK(0)
+    } else {
     // five requests per lane in flight, then their five LDS stores (one request per iteration waited a memory latency
     // nine times: 13 k of a frame's 88 k cycles; wider batches cost registers this kernel does not have)
     for (int base = lane; base <= mp; base += 320) {
@@ -707,6 +807,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
         for (int i = lane; i < nl; i += 64) yo[i] = y[i];
     }
     wave_sync();
+    }   // CMND formed here
 
     OBS_TICK(2)
     // troughs: util.localmin plus the special first element; contiguous lag chunk per lane
@@ -1167,17 +1268,27 @@ hipError_t viterbi_configure() {
     return viterbi_set_lds_limits();
 }
 
+// frames per workgroup of a batch launch: as many as keep two workgroups on a CU (16 at the reference's rates)
+static int frame_batch_fpw(int max_period) {
+    const int stride = frame_en_stride(max_period);
+    int fpw = kFramesPerWg;
+    while (fpw > 2 && kFrameLdsFixed + (size_t)fpw * stride * 4 > 80 * 1024) fpw -= 2;
+    return fpw;
+}
+bool frame_cmnd_supported(int max_period) {
+    // the epilogue keeps three lags per thread and frame in registers and one row per frame in the LDS the loop has freed
+    if (max_period + 1 > 3 * 256) return false;
+    const int stride = frame_en_stride(max_period), rs = frame_cmnd_stride(max_period);
+    for (int fpw : {2, frame_batch_fpw(max_period)})
+        if ((size_t)fpw * rs * 8 + 64 > kFrameLdsFixed + (size_t)fpw * stride * 4) return false;
+    return true;
+}
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
     if (p.n_sel == 0 || !(p.stages & 0xFu)) return;
     const int stride = frame_en_stride(p.max_period);
-    // batch launches: as many frames per workgroup as keep two workgroups on a CU (16 at the reference's rates); the
-    // running-energy prologue is one serial walk per workgroup, so small launches (streaming pushes) take a pair each
-    int fpw = 2;
-    if (p.n_sel >= 4096) {
-        fpw = kFramesPerWg;
-        while (fpw > 2 && kFrameLdsFixed + (size_t)fpw * stride * 4 > 80 * 1024) fpw -= 2;
-    }
-    size_t lds = kFrameLdsFixed + (size_t)fpw * stride * 4;
+    // the running-energy prologue is one serial walk per workgroup, so small launches (streaming pushes) take a pair each
+    const int fpw = p.n_sel >= 4096 ? frame_batch_fpw(p.max_period) : 2;
+    size_t lds = kFrameLdsFixed + (size_t)fpw * stride * 4 + (size_t)fpw * 8;     // + the frames' workspace rows (epilogue)
     // AEGIS_FRAME_LDS_MIN=<bytes> (experiment knob): ask for at least that much LDS, e.g. 100000 keeps one workgroup per CU
     static const size_t lds_min = [] { const char *e = std::getenv("AEGIS_FRAME_LDS_MIN"); return e ? (size_t)std::atol(e) : (size_t)0; }();
     lds = std::max(lds, std::min<size_t>(lds_min, 160 * 1024));
