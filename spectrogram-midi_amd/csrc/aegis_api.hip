@@ -1700,13 +1700,13 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     else if (n == "frame_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;
         if (dst && cap > 0) {
-            long long v[16];
+            long long v[24];
             HIPCHK(h, hipSetDevice(h->device));
             HIPCHK(h, hipDeviceSynchronize());
             HIPCHK(h, frame_debug_fetch(v));
-            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 24) * 8);
         }
-        return 16;
+        return 24;
     }
     else if (n == "viterbi_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;

@@ -223,7 +223,7 @@ __device__ __forceinline__ void cmnd_walk(double *__restrict__ r, int mp) {
 constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1040 * 4 + 128 * 4 + 16 * 4 + 256 * 4;
 
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-__device__ long long g_frm_dbg[16];
+__device__ long long g_frm_dbg[24];
 #define FRM_TICK(k) { __builtin_amdgcn_s_waitcnt(0); const long long now__ = clock64(); facc[k] += now__ - flast; flast = now__; }
 #else
 #define FRM_TICK(k)
@@ -634,13 +634,13 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         FRM_TICK(9)
     }
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-    if (blockIdx.x == 1000 && (tid == 0 || tid == 64)) { for (int k = 0; k < 7; ++k) g_frm_dbg[(tid ? 8 : 0) + k] = facc[k]; if (tid == 0) { g_frm_dbg[7] = facc[7] + facc[8] + facc[9]; } }
+    if (blockIdx.x == 1000 && (tid == 0 || tid == 64)) { for (int k = 0; k < 10; ++k) g_frm_dbg[(tid ? 12 : 0) + k] = facc[k]; }
 #endif
 }
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
-hipError_t frame_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_frm_dbg), sizeof(long long) * 16); }
+hipError_t frame_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_frm_dbg), sizeof(long long) * 24); }
 #else
-hipError_t frame_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
+hipError_t frame_debug_fetch(long long *dst) { for (int i = 0; i < 24; ++i) dst[i] = 0; return hipSuccess; }
 #endif
 
 // ------------------------------------------------------------------------------------------

@@ -11,9 +11,10 @@ clips = [np.roll(y, 1000 * i) for i in range(64)]
 h = _lib.Handle()
 h.analyze_batch(clips)
 v = h.debug_fetch("frame_cycles")
-names = ["energy prologue", "wait samples", "rms + fwd fft", "separate + power", "mel", "inverse fft", "difference store"]
-for base, who in ((0, "thread 0 (wave 0)"), (8, "thread 64 (wave 1)")):
-    tot = int(v[base:base + 7].sum())
+names = ["energy prologue", "wait samples", "rms + fwd fft", "separate + power", "mel", "inverse fft", "difference store",
+         "CMND: rows back", "CMND: cumsum walk", "CMND: quotients"]
+for base, who in ((0, "thread 0 (wave 0)"), (12, "thread 64 (wave 1)")):
+    tot = int(v[base:base + 10].sum())
     print(who, "total", tot, "clock64 ticks" )
-    for n, c in zip(names, v[base:base + 7]):
+    for n, c in zip(names, v[base:base + 10]):
         print(f"  {n:18s} {int(c):9d}  {100.0 * c / max(tot, 1):5.1f} %")
