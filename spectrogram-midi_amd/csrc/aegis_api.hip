@@ -48,6 +48,7 @@ struct aegis_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
+    bool cmnd_off = false;                    // AEGIS_CMND_IN_FRAME=0 at create: pyin_obs_kernel walks the CMND cumsum (tests compare the two paths)
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
@@ -177,10 +178,10 @@ PassParams base_params(const Tables &t) {
 }
 
 // The frame kernel's epilogue forms the CMND unless the stage tests want the difference function and the CMND as separate
-// buffers (AEGIS_DEBUG_STAGES=1), the experiment knob AEGIS_CMND_IN_FRAME=0 is set, or the lag range does not fit its LDS.
+// buffers (AEGIS_DEBUG_STAGES=1), AEGIS_CMND_IN_FRAME=0 was set when the handle was created, or the lag range does not fit
+// its LDS.
 int cmnd_in_frame(const aegis_handle *h) {
-    static const bool off = [] { const char *e = std::getenv("AEGIS_CMND_IN_FRAME"); return e && e[0] == '0'; }();
-    return (!off && !h->debug_stages && frame_cmnd_supported(h->tab.max_period)) ? 1 : 0;
+    return (!h->cmnd_off && !h->debug_stages && frame_cmnd_supported(h->tab.max_period)) ? 1 : 0;
 }
 
 void free_buf(DevBuf &b) {
@@ -289,6 +290,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
         if (v >= 64 && v % kViterbiChunk == 0) h->time_chunk = v;
     }
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
+    if (const char *e = std::getenv("AEGIS_CMND_IN_FRAME")) h->cmnd_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }

@@ -193,6 +193,29 @@ def test_dead_voiced_waves_skip_their_steps(eng):
     assert st["skipped"] == 7 * (F - 1)          # silence: no voiced target is ever observed
 
 
+@pytest.mark.parametrize("sr,hop", [(44100, 512), (22050, 256), (48000, 512)])
+def test_cmnd_in_the_frame_kernel_equals_the_walk_in_pyin_obs(sr, hop, monkeypatch):
+    """kernels.hip: the frame kernel's epilogue forms the CMND of a workgroup's 16 frames at once (what runs); with
+    AEGIS_CMND_IN_FRAME=0 at create, pyin_obs_kernel walks the cumsum frame by frame as before (what the stage tests and lag
+    ranges the epilogue cannot hold use).  Same operations in the same order: every output bit-identical, on a ragged batch
+    whose workgroups straddle clips, with a clip shorter than one hop and an empty one."""
+    rng = np.random.default_rng(5)
+    clips = [signals.guitar_clip(2.0 + 0.37 * i, sr=sr, seed=20 + i) for i in range(5)]
+    clips += [np.zeros(0, np.float32), (0.1 * rng.standard_normal(hop // 2)).astype(np.float32), signals.guitar_clip(1.0, sr=sr, seed=31, noise_dbfs=-10.0)]
+    outs = []
+    for knob in ("1", "0"):
+        monkeypatch.setenv("AEGIS_CMND_IN_FRAME", knob)
+        h = _lib.Handle(sample_rate=sr, hop_length=hop)
+        outs.append(h.analyze_batch(clips, stages=_lib.STAGE_PYIN))
+        h.close()
+    for a, b in zip(*outs):
+        for k in ("f0", "voiced_flag", "voiced_prob"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    f0, vf, vp = opyin.pyin(clips[1], sr=sr, hop_length=hop)
+    np.testing.assert_array_equal(outs[0][1]["voiced_flag"], vf)
+    np.testing.assert_array_equal(outs[0][1]["voiced_prob"], vp)
+
+
 def test_pyin_worker(eng):
     chunk = signals.guitar_clip(3.0, seed=4)
     f0, vf, vp = _pyin_worker((chunk, 44100, 512))
