@@ -52,6 +52,7 @@ struct aegis_handle {
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
+    int64_t feed_chunk = 1024;                // chunk size of balanced passes fed from host memory (AEGIS_FEED_CHUNK)
     int64_t balanced_chunk = 384;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
     int64_t balanced_ends = 64;               // first chunk of a balanced pass with a single Viterbi launch, doubling up to the chunk size and mirrored at the end (AEGIS_BALANCED_ENDS, 0 = off)
     int balanced_min = 16;                    // fewest clips of a balanced pass (AEGIS_BALANCED_MIN)
@@ -294,6 +295,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
+    if (const char *e = std::getenv("AEGIS_FEED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= kViterbiChunk && v % kViterbiChunk == 0) h->feed_chunk = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_ENDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->balanced_ends = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
     if (const char *e = std::getenv("AEGIS_VITERBI_PERSISTENT")) h->persistent = h->persistent_wanted = std::atoi(e) != 0;
@@ -431,6 +433,9 @@ struct HostFeed {
     std::vector<int64_t> copied;  // samples of each clip already enqueued
 };
 
+// sync: 0 = return with the work enqueued, 1 = synchronise and report (give-up of the single Viterbi launch, non-finite
+// samples), 2 = the caller synchronises and makes those checks itself right away (aegis_analyze_batch: the single Viterbi
+// launch is allowed, as with 1)
 static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets,
                                  int32_t n_clips, double rake_sensitivity, uint32_t stages,
                                  aegis_outputs *dout, void *stream_v, int32_t sync, HostFeed *feed = nullptr);
@@ -627,10 +632,15 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // 64 clips and scaled so that a chunk's observation kernel is ONE full round of workgroups on the frame stage's
         // 192 CUs (2 x 192 workgroups of 32 frames = 12 288 frames = 192 steps x 64 clips) and its frame kernel two:
         // 224 steps instead of 192 leave a sixth of a second round behind (54.1 instead of 50.6 ms).
-        const bool may_persist = balanced && h->persistent && sync && viterbi_band_applies(base_params(t), h->dt);
+        // A pass fed from host memory (aegis_analyze_batch) copies each chunk's samples from the thread that launches its
+        // kernels, and a pageable copy returns only when the bytes have left the caller's buffer: chunks of 192 steps are
+        // 5 000 copies of 0.4 MB per 64 x 180 s, and the single launch spins on flags that thread is late to set (64 x
+        // 180 s: 108 ms; a launch per chunk: 70).  Such a pass takes 1 024-step chunks (2 MB per clip and copy) and a launch
+        // per chunk: 57 ms, against 63 on the unbalanced schedule it used before and 49.4 device-resident.
+        const bool may_persist = balanced && !feed && h->persistent && sync && viterbi_band_applies(base_params(t), h->dt);
         int64_t kTimeChunk = h->time_chunk;
         if (balanced) {
-            const int64_t at64 = may_persist ? h->balanced_chunk / 2 : h->balanced_chunk;
+            const int64_t at64 = feed ? h->feed_chunk : (may_persist ? h->balanced_chunk / 2 : h->balanced_chunk);
             kTimeChunk = std::max<int64_t>(kViterbiChunk, at64 * 64 / nc / kViterbiChunk * kViterbiChunk);
         }
         std::vector<int64_t> cb{0};
@@ -878,7 +888,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         const int64_t lo = sample_offsets[0], hi = sample_offsets[n_clips];
         launch_finite_check(d_pcm + lo, hi - lo, static_cast<unsigned long long *>(h->finite_flag.p), s);
     }
-    if (sync) {
+    if (sync == 1) {
         HIPCHK(h, hipStreamSynchronize(s));
         h->metas.clear();
         if (h->profiling) collect_events(h);
@@ -911,7 +921,8 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if ((rc = ensure(h, h->io_pcm, (size_t)std::max<int64_t>(off[n_clips], 1) * 4)) != AEGIS_OK) return rc;
     hipStream_t s = h->stream;
     // the previous call's kernels may still read io_pcm only if it returned without a sync -- it never does
-    HostFeed feed{pcm, static_cast<float *>(h->io_pcm.p), std::vector<int64_t>((size_t)n_clips, 0)};
+    if (!h->persistent && h->persistent_wanted && h->persist_cooldown > 0 && --h->persist_cooldown == 0)
+        h->persistent = true;                 // as in aegis_analyze_batch_device: a give-up is not for good
     aegis_outputs d{};
     const int nm = h->tab.n_mels;
     if ((stages & AEGIS_STAGE_PYIN) && out->f0) { if ((rc = ensure(h, h->io_f0, F * 8))) return rc; d.f0 = static_cast<double *>(h->io_f0.p); }
@@ -922,9 +933,22 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
     if ((stages & AEGIS_STAGE_RMS) && out->rms) { if ((rc = ensure(h, h->io_rms, F * 4))) return rc; d.rms = static_cast<float *>(h->io_rms.p); }
     if ((stages & AEGIS_STAGE_RAKE) && out->rake_mask) { if ((rc = ensure(h, h->io_rake, F))) return rc; d.rake_mask = static_cast<uint8_t *>(h->io_rake.p); }
     if ((stages & AEGIS_STAGE_MEL) && out->S_dB) { if ((rc = ensure(h, h->io_sdb, F * nm * 4))) return rc; d.S_dB = static_cast<float *>(h->io_sdb.p); }
-    rc = analyze_device_locked(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
-                               rake_sensitivity, stages, &d, s, 0, &feed);
-    if (rc != AEGIS_OK) return rc;
+    for (int attempt = 0;; ++attempt) {
+        // stream_v = NULL (the handle's own stream) and sync = 2: the schedule the device-pointer entry takes with
+        // sync = 1, single Viterbi launch included -- this function synchronises below
+        HostFeed feed{pcm, static_cast<float *>(h->io_pcm.p), std::vector<int64_t>((size_t)n_clips, 0)};
+        rc = analyze_device_locked(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
+                                   rake_sensitivity, stages, &d, nullptr, 2, &feed);
+        if (rc != AEGIS_OK) return rc;
+        if (!h->persist_pending) break;
+        HIPCHK(h, hipStreamSynchronize(s));
+        if ((rc = persistent_check(h)) == AEGIS_OK) break;
+        if (!h->persist_gave_up || attempt > 0) return rc;
+        h->persist_gave_up = false;           // one launch per chunk for the next 16 calls, and this call again
+        h->persistent = false;
+        h->persist_cooldown = 16;
+        ++h->persistent_fallbacks;
+    }
     if (d.f0) HIPCHK(h, hipMemcpyAsync(out->f0, d.f0, F * 8, hipMemcpyDeviceToHost, s));
     if (d.voiced_flag) HIPCHK(h, hipMemcpyAsync(out->voiced_flag, d.voiced_flag, F, hipMemcpyDeviceToHost, s));
     if (d.sdb_col_means) HIPCHK(h, hipMemcpyAsync(out->sdb_col_means, d.sdb_col_means, F * 12, hipMemcpyDeviceToHost, s));
