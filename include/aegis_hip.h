@@ -202,6 +202,21 @@ void aegis_stream_free(aegis_stream *st);
 int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
                 const double *params, int32_t n_params, void *const *outs, int32_t n_outs);
 
+/* The ghost-note filter's RSI lookup for a batch of clips in one call (FinancialPitchAnalyzer.filter_ghost_notes_rsi,
+ * /root/reference/aegis_engine_core_v2/financial_analysis.py:322-362).  The reference adds 1 over [int(start*10), int(end*10))
+ * per note to a density track of int(max_end*10) elements, takes the RSI of the track (period 14) and reads it at
+ * int(start*10) of every note.  Here the tracks are built on the device from the notes' intervals and only the two Wilder
+ * averages at each note's own position come back (avg_gain, avg_loss: the caller forms 100 - 100 / (1 + gain / loss), the
+ * reference's operations; NaN where the RSI is the constant 50 of the first `period` positions or of a track shorter than
+ * period + 1, and where the position lies outside the track).  The same values as AEGIS_TREND_RSI (averages = 1) on the
+ * density tracks, without materialising 77 k elements per three-minute clip on the host.
+ *   ev_a, ev_b      [event_off[n_series]]  int(start*10), int(end*10) of every note, clip after clip
+ *   event_off       [n_series + 1]         first note of each clip
+ *   track_len       [n_series]             int(max_end * 10) of each clip (0: the clip is skipped)
+ *   avg_gain, avg_loss  [event_off[n_series]]  host, written */
+int aegis_ghost_rsi(aegis_handle *h, const int64_t *ev_a, const int64_t *ev_b, const int64_t *event_off, int32_t n_series,
+                    const int64_t *track_len, int32_t period, double *avg_gain, double *avg_loss);
+
 /* --- note events and Standard MIDI Files for a batch of clips: host code, no GPU, no handle ----------------
  * SURVEY.md 8(f) rank 1.  aegis_extract_events replaces get_midi_events + detect_articulations
  * (aegis_engine_core/midi_logic.py:32-148, 6-30) from the point where the frame arrays are gated: the caller passes,

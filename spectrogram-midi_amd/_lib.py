@@ -40,7 +40,7 @@ class Outputs(C.Structure):
 
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
-           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend",
+           "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend", "aegis_ghost_rsi",
            "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt", "aegis_cqt_device",
            "aegis_extract_events", "aegis_render_smf", "aegis_events_last_error")
 
@@ -77,6 +77,8 @@ def load():
     lib.aegis_trend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
                                 C.POINTER(C.c_void_p), C.c_int32]
     lib.aegis_trend.restype = C.c_int
+    lib.aegis_ghost_rsi.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.aegis_ghost_rsi.restype = C.c_int
     lib.aegis_stream_open.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
     lib.aegis_stream_open.restype = C.c_int
     lib.aegis_stream_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(StreamFrames), C.POINTER(C.c_int64)]
@@ -303,6 +305,18 @@ class Handle:
         self._check(self.lib.aegis_trend(self._h, int(op), flat.ctypes.data, off.ctypes.data, len(lens),
                                          par.ctypes.data, len(par), ptrs, n_out))
         return [[o[off[i]:off[i + 1]] for i in range(len(lens))] for o in outs]
+
+    def ghost_rsi(self, ev_a, ev_b, event_off, track_len, period=14):
+        """aegis_ghost_rsi: the Wilder averages (avg_gain, avg_loss) of every clip's ghost-note density track at its notes'
+        own positions; ev_a / ev_b = int(start*10) / int(end*10) of the notes clip after clip, event_off their offsets."""
+        a = np.ascontiguousarray(ev_a, dtype=np.int64)
+        b = np.ascontiguousarray(ev_b, dtype=np.int64)
+        off = np.ascontiguousarray(event_off, dtype=np.int64)
+        tl = np.ascontiguousarray(track_len, dtype=np.int64)
+        g, l = np.full(len(a), np.nan), np.full(len(a), np.nan)
+        self._check(self.lib.aegis_ghost_rsi(self._h, a.ctypes.data, b.ctypes.data, off.ctypes.data, len(tl), tl.ctypes.data,
+                                             int(period), g.ctypes.data, l.ctypes.data))
+        return g, l
 
     def cqt(self, clips, n_bins=84, bins_per_octave=12, fmin=32.70319566257483, filter_scale=1.0):
         """|CQT| of each clip, float32 [n_bins, 1 + len//hop] (aegis_cqt: direct transform on the MFMA units)."""

@@ -1388,6 +1388,51 @@ int aegis_stream_close(aegis_stream *st, double rake_sensitivity, aegis_outputs 
     } catch (...) { return abi_fail((st ? st->h : nullptr)); }
 }
 
+int aegis_ghost_rsi(aegis_handle *h, const int64_t *ev_a, const int64_t *ev_b, const int64_t *event_off, int32_t n_series,
+                    const int64_t *track_len, int32_t period, double *avg_gain, double *avg_loss) {
+    try {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_series < 0 || (n_series > 0 && (!event_off || !track_len))) { h->err = "bad argument"; return AEGIS_ERR_INVALID; }
+    if (period < 1 || period > 128) { h->err = "rsi period must be 1..128"; return AEGIS_ERR_INVALID; }
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    if (n_series == 0) return AEGIS_OK;
+    const int64_t E = event_off[n_series] - event_off[0];
+    if (E < 0) { h->err = "event_off must be non-decreasing"; return AEGIS_ERR_INVALID; }
+    if (E == 0) return AEGIS_OK;
+    if (!ev_a || !ev_b || !avg_gain || !avg_loss) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    std::vector<int64_t> toff((size_t)n_series + 1, 0);
+    std::vector<int32_t> sid((size_t)E);
+    for (int i = 0; i < n_series; ++i) {
+        if (track_len[i] < 0 || event_off[i + 1] < event_off[i]) { h->err = "bad clip " + std::to_string(i); return AEGIS_ERR_INVALID; }
+        toff[(size_t)i + 1] = toff[(size_t)i] + track_len[i];
+        for (int64_t e = event_off[i]; e < event_off[i + 1]; ++e) sid[(size_t)(e - event_off[0])] = i;
+    }
+    const int64_t total = toff[(size_t)n_series];
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+#define ENS(buf, bytes) if ((rc = ensure(h, h->buf, (size_t)(bytes))) != AEGIS_OK) return rc
+    ENS(t_x, std::max<int64_t>(total, 1) * 8); ENS(t_a, std::max<int64_t>(total, 1) * 8); ENS(t_b, std::max<int64_t>(total, 1) * 8);
+    ENS(t_off, (n_series + 1) * 8); ENS(t_i64a, 2 * E * 8); ENS(t_i64b, E * 4 + 8); ENS(t_c, 2 * E * 8);
+#undef ENS
+    int64_t *d_ab = static_cast<int64_t *>(h->t_i64a.p);
+    int32_t *d_sid = static_cast<int32_t *>(h->t_i64b.p);
+    double *d_out = static_cast<double *>(h->t_c.p);
+    HIPCHK(h, hipMemcpyAsync(d_ab, ev_a + event_off[0], (size_t)E * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_ab + E, ev_b + event_off[0], (size_t)E * 8, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(d_sid, sid.data(), (size_t)E * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(h->t_off.p, toff.data(), ((size_t)n_series + 1) * 8, hipMemcpyHostToDevice, s));
+    trend_ghost_rsi(d_ab, d_ab + E, d_sid, E, static_cast<const int64_t *>(h->t_off.p), n_series, total, period,
+                    static_cast<double *>(h->t_x.p), static_cast<double *>(h->t_a.p), static_cast<double *>(h->t_b.p), d_out, d_out + E, s);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(avg_gain + event_off[0], d_out, (size_t)E * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(avg_loss + event_off[0], d_out + E, (size_t)E * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
+}
+
 int aegis_trend(aegis_handle *h, int32_t op, const double *x, const int64_t *offsets, int32_t n_series,
                 const double *params, int32_t n_params, void *const *outs, int32_t n_outs) {
     try {

@@ -22,6 +22,11 @@ void trend_semitones(const double *x, int64_t total, double *out, hipStream_t s)
 void trend_slides(const double *macd, const double *hist, int64_t total, double thr, int8_t *codes, hipStream_t s);
 void trend_rsi(const TrendArgs &a, int period, double *out, hipStream_t s);
 void trend_rsi_averages(const TrendArgs &a, int period, double *avg_gain, double *avg_loss, hipStream_t s);
+// density tracks of the ghost-note filter from the notes' [a, b) intervals, their Wilder averages (rsi_kernel<true>) and the
+// averages at the notes' own positions; density / ag / al: scratch of `total` doubles, off: [n_series + 1] track offsets
+void trend_ghost_rsi(const int64_t *ev_a, const int64_t *ev_b, const int32_t *ev_series, int64_t n_events, const int64_t *off,
+                     int n_series, int64_t total, int period, double *density, double *ag, double *al, double *out_g, double *out_l,
+                     hipStream_t s);
 void trend_savgol(const TrendArgs &a, const double *coef_rev, int window, int symmetric, double *cx, int64_t *cpos,
                   int64_t *ccount, double *out, hipStream_t s);
 void trend_kalman(const TrendArgs &a, double q, double r, double *out, hipStream_t s);

@@ -514,6 +514,81 @@ void trend_rsi(const TrendArgs &a, int period, double *out, hipStream_t s) {
 void trend_rsi_averages(const TrendArgs &a, int period, double *avg_gain, double *avg_loss, hipStream_t s) {
     if (a.n_series) hipLaunchKernelGGL(rsi_kernel<true>, dim3(blocks(a.n_series, 64)), dim3(64), 0, s, a.x, a.off, a.n_series, period, avg_gain, avg_loss);
 }
+// ---- ghost-note density tracks (financial_analysis.py:333-347) built on the device -----------------------------------------
+// The filter adds 1 over [start*10, end*10) per note to a track of int(max_end * 10) elements (77 k for a three-minute
+// clip) and reads the RSI of that track at the notes' start positions.  The counts are small integers, exact in float64
+// whatever the order of the additions, so the track is a difference array (two atomic adds per note) and a parallel
+// prefix sum; only the Wilder averages at the notes' own positions go back to the host.
+__global__ __launch_bounds__(256) void ghost_diff_kernel(const int64_t *__restrict__ ev_a, const int64_t *__restrict__ ev_b,
+                                                         const int32_t *__restrict__ ev_series, int64_t n_events,
+                                                         const int64_t *__restrict__ off, double *__restrict__ d) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    const int s = ev_series[e];
+    const int64_t base = off[s], n = off[s + 1] - base;
+    const int64_t a = ev_a[e], b = min(ev_b[e], n);
+    if (a < 0 || a >= n || b <= a) return;
+    atomicAdd(d + base + a, 1.0);
+    if (b < n) atomicAdd(d + base + b, -1.0);
+}
+// in-place inclusive prefix sum of every series, one workgroup per series (exact: integer values)
+__global__ __launch_bounds__(256) void ghost_scan_kernel(const int64_t *__restrict__ off, double *__restrict__ d) {
+    constexpr int PER = 8, TILE = 256 * PER;
+    __shared__ double wsum[4];
+    __shared__ double carry_s;
+    const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+    double *x = d + off[s];
+    const int64_t n = off[s + 1] - off[s];
+    if (tid == 0) carry_s = 0.0;
+    __syncthreads();
+    for (int64_t t0 = 0; t0 < n; t0 += TILE) {
+        double v[PER];
+        double run = 0.0;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t i = t0 + (int64_t)tid * PER + k;
+            run += i < n ? x[i] : 0.0;
+            v[k] = run;
+        }
+        double incl = run;                     // inclusive scan of the threads' sums over the wave, then over the 4 waves
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const double nb = __shfl_up(incl, o); if (lane >= o) incl += nb; }
+        if (lane == 63) wsum[wid] = incl;
+        __syncthreads();
+        double before = carry_s + (incl - run);
+        for (int w = 0; w < wid; ++w) before += wsum[w];
+#pragma unroll
+        for (int k = 0; k < PER; ++k) {
+            const int64_t i = t0 + (int64_t)tid * PER + k;
+            if (i < n) x[i] = before + v[k];
+        }
+        __syncthreads();
+        if (tid == 255) carry_s = before + run;
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(256) void ghost_gather_kernel(const int64_t *__restrict__ ev_a, const int32_t *__restrict__ ev_series,
+                                                           int64_t n_events, const int64_t *__restrict__ off,
+                                                           const double *__restrict__ ag, const double *__restrict__ al,
+                                                           double *__restrict__ out_g, double *__restrict__ out_l) {
+    const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= n_events) return;
+    const int s = ev_series[e];
+    const int64_t base = off[s], n = off[s + 1] - base, a = ev_a[e];
+    const bool in = a >= 0 && a < n;
+    out_g[e] = in ? ag[base + a] : (double)NAN;
+    out_l[e] = in ? al[base + a] : (double)NAN;
+}
+void trend_ghost_rsi(const int64_t *ev_a, const int64_t *ev_b, const int32_t *ev_series, int64_t n_events, const int64_t *off,
+                     int n_series, int64_t total, int period, double *density, double *ag, double *al, double *out_g, double *out_l,
+                     hipStream_t s) {
+    if (!n_events || !n_series) return;
+    (void)hipMemsetAsync(density, 0, (size_t)total * 8, s);
+    hipLaunchKernelGGL(ghost_diff_kernel, dim3(blocks(n_events, 256)), dim3(256), 0, s, ev_a, ev_b, ev_series, n_events, off, density);
+    hipLaunchKernelGGL(ghost_scan_kernel, dim3(n_series), dim3(256), 0, s, off, density);
+    hipLaunchKernelGGL(rsi_kernel<true>, dim3(blocks(n_series, 64)), dim3(64), 0, s, density, off, n_series, period, ag, al);
+    hipLaunchKernelGGL(ghost_gather_kernel, dim3(blocks(n_events, 256)), dim3(256), 0, s, ev_a, ev_series, n_events, off, ag, al, out_g, out_l);
+}
 void trend_savgol(const TrendArgs &a, const double *coef_rev, int window, int symmetric, double *cx, int64_t *cpos,
                   int64_t *ccount, double *out, hipStream_t s) {
     if (!a.total) return;

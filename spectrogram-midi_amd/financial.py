@@ -149,17 +149,25 @@ class FinancialPitchAnalyzer:
         """filter_ghost_notes_rsi for several clips: every clip's density track is one series of ONE library call, which
         returns the two Wilder averages; the RSI value (avg_gain / avg_loss -> 100 - 100 / (1 + rs), the reference's
         operations) is then formed at the few positions the filter reads."""
-        dens = [self._ghost_density(ev) if ev else np.zeros(0) for ev in event_lists]
-        live = [i for i, d in enumerate(dens) if len(d)]
         out = list(event_lists)
+        live = [i for i, ev in enumerate(event_lists) if ev]
         if not live:
             return out
-        ag, al = _handle(self.device).trend(_lib.TREND_RSI, [dens[i] for i in live], [14, 1], n_out=2)
+        # int(start * 10), int(end * 10) of every note and int(max_end * 10) per clip: all the library needs to build the
+        # density tracks on the device (aegis_ghost_rsi); the tracks themselves (77 k elements per three-minute clip)
+        # never exist on the host
+        counts = [len(event_lists[i]) for i in live]
+        off = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        starts = np.fromiter((e["start"] for i in live for e in event_lists[i]), dtype=np.float64, count=int(off[-1]))
+        ends = np.fromiter((e["end"] for i in live for e in event_lists[i]), dtype=np.float64, count=int(off[-1]))
+        a, b = (starts * 10).astype(np.int64), (ends * 10).astype(np.int64)
+        n = np.array([int(ends[off[j]:off[j + 1]].max() * 10) for j in range(len(live))], dtype=np.int64)
+        g_all, l_all = _handle(self.device).ghost_rsi(a, b, off, n, period=14)
         for j, i in enumerate(live):
             ev = event_lists[i]
-            idx = np.array([int(e["start"] * 10) for e in ev])
-            inside = idx < len(dens[i])
-            g, l = ag[j][idx[inside]], al[j][idx[inside]]
+            sl = slice(int(off[j]), int(off[j + 1]))
+            inside = a[sl] < n[j]
+            g, l = g_all[sl][inside], l_all[sl][inside]
             with np.errstate(divide="ignore", invalid="ignore"):
                 val = 100 - (100 / (1 + g / l))
             val = np.where(l == 0, 100.0, val)

@@ -92,6 +92,37 @@ def test_analyze_pitch_financial():
             close(r["confidence"], G[f"{n}/apf_{tag}_conf"], f"{n} conf {tag}", rtol=1e-9)
 
 
+def test_ghost_rsi_on_the_device_equals_the_rsi_of_the_density_tracks():
+    """aegis_ghost_rsi builds the density tracks from the notes' intervals on the device and returns the Wilder averages at
+    the notes' own positions: bit-identical to AEGIS_TREND_RSI (averages) on the tracks the host would have built
+    (FinancialPitchAnalyzer._ghost_density), including notes that start at the end of the track, tracks shorter than the
+    period, a clip whose notes all end before 0.1 and frame-unit times (tracks of tens of thousands of elements)."""
+    from spectrogram_midi_amd.financial import _handle
+    rng = np.random.default_rng(11)
+    lists = []
+    for n_notes, span in ((40, 300.0), (12, 7752.0), (300, 7752.0), (3, 1.0), (2, 0.05), (25, 60.0)):
+        st = np.sort(rng.uniform(0, span, n_notes))
+        lists.append([{"start": float(a), "end": float(a + rng.uniform(0.001, max(span / 10, 0.002)))} for a in st])
+    lists[1][-1]["start"] = lists[1][-1]["end"] = max(e["end"] for e in lists[1])          # a note at the very end of its track
+    h = _handle(0)
+    off = np.concatenate([[0], np.cumsum([len(ev) for ev in lists])]).astype(np.int64)
+    starts = np.array([e["start"] for ev in lists for e in ev]); ends = np.array([e["end"] for ev in lists for e in ev])
+    a, b = (starts * 10).astype(np.int64), (ends * 10).astype(np.int64)
+    n = np.array([int(max(e["end"] for e in ev) * 10) for ev in lists], dtype=np.int64)
+    g, l = h.ghost_rsi(a, b, off, n)
+    for j, ev in enumerate(lists):
+        dens = an._ghost_density(ev)
+        assert len(dens) == n[j]
+        sl = slice(int(off[j]), int(off[j + 1]))
+        inside = a[sl] < n[j]
+        assert np.isnan(g[sl][~inside]).all() and np.isnan(l[sl][~inside]).all()
+        if n[j] == 0:
+            continue
+        ag, al = h.trend(_lib.TREND_RSI, [dens], [14, 1], n_out=2)
+        np.testing.assert_array_equal(g[sl][inside], ag[0][a[sl][inside]])
+        np.testing.assert_array_equal(l[sl][inside], al[0][a[sl][inside]])
+
+
 def test_ghost_note_filter_matches_reference():
     cases = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "v2_harmonic_golden.json")))
     lists, want = [], []
