@@ -562,6 +562,41 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         }
         FRM_TICK(5)
         // FFT(conj Q) = N * conj(acf0 + i acf1); difference function with librosa's clamps (pitch.py::_cumulative_mean_normalized_difference)
+        // With the CMND formed in this kernel's epilogue, the FIRST frame's row stays in LDS: the pair's two energy rows are
+        // dead once read, and together they are exactly one float64 row (8 (max_period + 1) <= 8 en_stride bytes).  Only the
+        // second frame's row makes the trip through global memory and back.
+        const bool keep_first = p.cmnd_in_frame != 0;
+        if (keep_first) {
+            double dq[2][3];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float *row = en + (pr + h) * en_stride;
+                float en0 = row[0];
+                if (fabsf(en0) < 1e-6f) en0 = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    const int tau = min(tid + 256 * u, mp);
+                    const double2 zz = z[zsw(1024 + tau)];
+                    double a = (h == 0 ? zz.x : -zz.y) * (1.0 / 2048.0);
+                    if (fabs(a) < 1e-6) a = 0.0;
+                    float e = row[tau];
+                    if (fabsf(e) < 1e-6f) e = 0.0f;
+                    const float esum = en0 + e;
+                    dq[h][u] = (double)esum - 2.0 * a;
+                }
+            }
+            __syncthreads();                 // every thread has read its energies: the two rows become the first frame's d row
+            double *__restrict__ d0 = reinterpret_cast<double *>(en + pr * en_stride);
+            double *__restrict__ d1 = p.dfn + fidx[1] * (int64_t)p.lag_stride;
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int tau = tid + 256 * u;
+                if (tau <= mp) {
+                    if (flive[0]) d0[tau] = dq[0][u];
+                    if (flive[1]) d1[tau] = dq[1][u];
+                }
+            }
+        } else {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             if (!flive[h]) continue;
@@ -579,6 +614,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 drow[tau] = (double)esum - 2.0 * a;
             }
         }
+        }
         // the next pair's first write into z (pass 1) comes after that frame's first barrier
         FRM_TICK(6)
     }
@@ -586,49 +622,53 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
     // yin[tau] = d[tau] / (cumsum(d[1:])[tau] / tau + tiny), pitch.py::_cumulative_mean_normalized_difference.  np.cumsum is
     // strictly sequential in float64: one lane per frame walks it, all frames of the workgroup in one wave's lanes at once
     // (pyin_obs_kernel spent a third of its time issuing whole-wave instructions for one lane's walk, frame after frame).
-    // Every LDS buffer is dead by now and together they hold the frames' rows; the d rows come back from L2 (this workgroup
-    // wrote them a moment ago) into registers and LDS, the walk turns the LDS copy into the cumsum in place, the quotients
-    // run on all threads from the register copy and go out over d[min_period..]: pyin_obs_kernel reads the CMND directly.
+    // The rows of the even frames never left LDS (the pair loop wrote them over the pair's energy rows); those of the odd
+    // frames come back from L2 / the fabric (this workgroup wrote them a moment ago) into the FFT buffer, which is dead by
+    // now.  Every thread keeps its share of d in registers, the walk turns the LDS copy into the cumsum in place, the
+    // quotients run on all threads and go out over d[min_period..]: pyin_obs_kernel reads the CMND directly.
     if (want_pyin && p.cmnd_in_frame) {
         const int RS = frame_cmnd_stride(mp), minp = p.min_period;
-        double *rows = reinterpret_cast<double *>(fsm);
-        __syncthreads();                         // the d rows are written (workgroup-scope release), LDS is free
+        // rows of the even frames: where the pair loop left them (over the pair's energy rows); rows of the odd frames: back
+        // from global memory into the FFT buffer / frame / power area
+        double *zrows = reinterpret_cast<double *>(fsm);
+        auto row_of = [&](int i) { return (i & 1) ? zrows + (i >> 1) * RS : reinterpret_cast<double *>(en + i * en_stride); };
+        __syncthreads();                         // the d rows are written (workgroup-scope release), the other LDS buffers are free
         double dv[kFramesPerWg][3];
         int64_t fr[kFramesPerWg];
 #pragma unroll
         for (int i = 0; i < kFramesPerWg; ++i) fr[i] = i < nfr ? frow[i] : -1;
-        __syncthreads();                         // frow sits behind the running energies: read before the rows may cover it
 #pragma unroll
         for (int i = 0; i < kFramesPerWg; ++i) {
-            const double *__restrict__ drow = p.dfn + (fr[i] < 0 ? 0 : fr[i]) * (int64_t)p.lag_stride;
+            const double *__restrict__ src = (i & 1) ? p.dfn + (fr[i] < 0 ? 0 : fr[i]) * (int64_t)p.lag_stride : row_of(i);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int tau = tid + 256 * u;
-                dv[i][u] = (fr[i] >= 0 && tau <= mp) ? drow[tau] : 0.0;
+                dv[i][u] = (fr[i] >= 0 && tau <= mp) ? src[tau] : 0.0;
             }
         }
 #pragma unroll
-        for (int i = 0; i < kFramesPerWg; ++i) {
+        for (int i = 1; i < kFramesPerWg; i += 2) {
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int tau = tid + 256 * u;
-                if (i < nfr && tau <= mp) rows[i * RS + tau] = dv[i][u];
+                if (i < nfr && tau <= mp) zrows[(i >> 1) * RS + tau] = dv[i][u];
             }
         }
         __syncthreads();
         FRM_TICK(7)
         if (wid == 0) __builtin_amdgcn_s_setprio(3);
-        if (wid == 0 && lane < nfr) cmnd_walk(rows + lane * RS, mp);
+        if (wid == 0 && lane < nfr) cmnd_walk(row_of(lane), mp);
         if (wid == 0) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         FRM_TICK(8)
 #pragma unroll
         for (int i = 0; i < kFramesPerWg; ++i) {
             double *__restrict__ drow = p.dfn + (fr[i] < 0 ? 0 : fr[i]) * (int64_t)p.lag_stride;
+            const double *__restrict__ cs = row_of(i);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int tau = tid + 256 * u;
-                if (fr[i] >= 0 && tau >= minp && tau <= mp) drow[tau] = dv[i][u] / (rows[i * RS + tau] / (double)tau + DBL_MIN);
+                if (fr[i] >= 0 && tau >= minp && tau <= mp) drow[tau] = dv[i][u] / (cs[tau] / (double)tau + DBL_MIN);
             }
         }
         FRM_TICK(9)
@@ -1279,8 +1319,9 @@ bool frame_cmnd_supported(int max_period) {
     // the epilogue keeps three lags per thread and frame in registers and one row per frame in the LDS the loop has freed
     if (max_period + 1 > 3 * 256) return false;
     const int stride = frame_en_stride(max_period), rs = frame_cmnd_stride(max_period);
-    for (int fpw : {2, frame_batch_fpw(max_period)})
-        if ((size_t)fpw * rs * 8 + 64 > kFrameLdsFixed + (size_t)fpw * stride * 4) return false;
+    if (stride < max_period + 1) return false;                   // a pair's two energy rows hold one float64 row
+    for (int fpw : {2, frame_batch_fpw(max_period)})               // the odd frames' rows share the fixed buffers
+        if ((size_t)(fpw / 2) * rs * 8 + 64 > kFrameLdsFixed) return false;
     return true;
 }
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s) {
