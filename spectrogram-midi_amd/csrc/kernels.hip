@@ -567,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         // second frame's row makes the trip through global memory and back.
         const bool keep_first = p.cmnd_in_frame != 0;
         if (keep_first) {
-            double dq[2][3];
+            float es[2][3];                  // en[0] + en[tau] of both frames (float32, librosa's clamps), read before the rows are overwritten
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const float *row = en + (pr + h) * en_stride;
@@ -575,14 +575,9 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 if (fabsf(en0) < 1e-6f) en0 = 0.0f;
 #pragma unroll
                 for (int u = 0; u < 3; ++u) {
-                    const int tau = min(tid + 256 * u, mp);
-                    const double2 zz = z[zsw(1024 + tau)];
-                    double a = (h == 0 ? zz.x : -zz.y) * (1.0 / 2048.0);
-                    if (fabs(a) < 1e-6) a = 0.0;
-                    float e = row[tau];
+                    float e = row[min(tid + 256 * u, mp)];
                     if (fabsf(e) < 1e-6f) e = 0.0f;
-                    const float esum = en0 + e;
-                    dq[h][u] = (double)esum - 2.0 * a;
+                    es[h][u] = en0 + e;
                 }
             }
             __syncthreads();                 // every thread has read its energies: the two rows become the first frame's d row
@@ -592,8 +587,12 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             for (int u = 0; u < 3; ++u) {
                 const int tau = tid + 256 * u;
                 if (tau <= mp) {
-                    if (flive[0]) d0[tau] = dq[0][u];
-                    if (flive[1]) d1[tau] = dq[1][u];
+                    const double2 zz = z[zsw(1024 + tau)];
+                    double a0 = zz.x * (1.0 / 2048.0), a1 = -zz.y * (1.0 / 2048.0);
+                    if (fabs(a0) < 1e-6) a0 = 0.0;
+                    if (fabs(a1) < 1e-6) a1 = 0.0;
+                    if (flive[0]) d0[tau] = (double)es[0][u] - 2.0 * a0;
+                    if (flive[1]) d1[tau] = (double)es[1][u] - 2.0 * a1;
                 }
             }
         } else {
