@@ -36,7 +36,7 @@ struct DevBuf {
 };
 
 struct PassMeta {   // host copies kept alive until the stream has consumed them
-    std::vector<int64_t> sample_off, sample_len, out_off, frame_off, chunk_off, sel_off, chunk_lo;
+    std::vector<int64_t> sample_off, sample_len, out_off, frame_off, chunk_off, sel_off, chunk_lo, clip_tb;
     std::vector<int32_t> order;
 };
 
@@ -52,6 +52,7 @@ struct aegis_handle {
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
+    bool proportional_chunks = true;          // ragged unbalanced passes cut every clip into the same number of chunks (AEGIS_PROPORTIONAL_CHUNKS=0: one time axis)
     int64_t feed_chunk = 1024;                // chunk size of balanced passes fed from host memory (AEGIS_FEED_CHUNK)
     int64_t balanced_chunk = 384;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
     int64_t balanced_ends = 64;               // first chunk of a balanced pass with a single Viterbi launch, doubling up to the chunk size and mirrored at the end (AEGIS_BALANCED_ENDS, 0 = off)
@@ -72,7 +73,7 @@ struct aegis_handle {
     // Viterbi of the previous one
     struct Work {
         DevBuf dfn, yin, logobs, logunv, obs_seg, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
-        DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate, chunk_lo, chunk_flag;
+        DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate, chunk_lo, chunk_flag, clip_tb;
     } work[2];
     int last_work = 0;
     DevBuf vstats, rk_raw, abort_flag, finite_flag;
@@ -295,6 +296,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
+    if (const char *e = std::getenv("AEGIS_PROPORTIONAL_CHUNKS")) h->proportional_chunks = e[0] != '0';
     if (const char *e = std::getenv("AEGIS_FEED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= kViterbiChunk && v % kViterbiChunk == 0) h->feed_chunk = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_ENDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->balanced_ends = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_MIN")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1) h->balanced_min = (int)v; }
@@ -384,7 +386,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (auto &w : h->work)
         for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.obs_seg, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
                           &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
-                          &w.vstate, &w.chunk_lo, &w.chunk_flag})
+                          &w.vstate, &w.chunk_lo, &w.chunk_flag, &w.clip_tb})
             free_buf(*b);
     for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->finite_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->t_pa, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
@@ -674,10 +676,41 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         const int nk = (int)cb.size() - 1;
         auto chunk_lo = [&](int k) { return cb[k]; };
         auto chunk_hi = [&](int k) { return cb[k + 1]; };
+        // Ragged passes: every clip is cut into the SAME nk chunks, each a share of the clip proportional to the chunk's
+        // share of the longest clip (boundaries stay on 1 + multiples of kViterbiChunk).  With one time axis for all clips
+        // the short clips are done after a few chunks and the last launches hold only the long clips' Viterbi workgroups
+        // on an otherwise idle chip (512-clip folder: the last 36 of 363 ms); with proportional chunks every launch
+        // carries every clip and all of them finish with the last chunk.  The results do not depend on the cut.
+        bool proportional = false;
+        if (py && !balanced && nk > 2 && h->proportional_chunks) {
+            int64_t minF = maxF;
+            for (int i = 0; i < nc; ++i) minF = std::min(minF, frames[pc[i]]);
+            proportional = 4 * minF < 3 * maxF;
+        }
+        // tb[k * nc + i]: first frame of chunk k of the pass's clip i (k = nk: its frame count)
+        m.clip_tb.clear();
+        if (proportional) {
+            m.clip_tb.assign((size_t)(nk + 1) * nc, 0);
+            for (int i = 0; i < nc; ++i) {
+                const int64_t Fc = frames[pc[i]];
+                int64_t prev = 0;
+                for (int k = 1; k <= nk; ++k) {
+                    int64_t b = Fc;
+                    if (k < nk) {
+                        const int64_t want = 1 + (int64_t)((double)(cb[k] - 1) * (double)Fc / (double)maxF) / kViterbiChunk * kViterbiChunk;
+                        b = std::min(Fc, std::max(want, prev == 0 ? 1 + kViterbiChunk : prev + kViterbiChunk));
+                    }
+                    m.clip_tb[(size_t)k * nc + i] = b;
+                    prev = b;
+                }
+            }
+        }
+        auto clip_lo = [&](int k, int i) { return proportional ? m.clip_tb[(size_t)k * nc + i] : std::min(frames[pc[i]], chunk_lo(k)); };
+        auto clip_hi = [&](int k, int i) { return proportional ? m.clip_tb[(size_t)(k + 1) * nc + i] : std::min(frames[pc[i]], chunk_hi(k)); };
         m.sel_off.assign((size_t)nk * (nc + 1), 0);
         for (int k = 0; k < nk; ++k)
             for (int i = 0; i < nc; ++i) {
-                const int64_t cnt = std::max<int64_t>(0, std::min(frames[pc[i]], chunk_hi(k)) - chunk_lo(k));
+                const int64_t cnt = std::max<int64_t>(0, clip_hi(k, i) - clip_lo(k, i));
                 m.sel_off[(size_t)k * (nc + 1) + i + 1] = m.sel_off[(size_t)k * (nc + 1) + i] + cnt;
             }
 
@@ -723,6 +756,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             ENS(ptr, fp * S * 2); ENS(cmap, (nchunks + 1) * S * 2); ENS(bnd, (nchunks + 1) * 4);
             ENS(states, fp * 4); ENS(vstate, (size_t)nc * S * 8);
             ENS(chunk_lo, (size_t)nk * 8); ENS(chunk_flag, (size_t)nk * 4);
+            if (proportional) ENS(clip_tb, (size_t)(nk + 1) * nc * 8);
         }
         if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
 #undef ENS
@@ -733,6 +767,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipMemcpyAsync(w.chunk_off.p, m.chunk_off.data(), (nc + 1) * 8, hipMemcpyHostToDevice, fa));
         HIPCHK(h, hipMemcpyAsync(w.order.p, m.order.data(), nc * 4, hipMemcpyHostToDevice, fa));
         HIPCHK(h, hipMemcpyAsync(w.sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, fa));
+        if (proportional) HIPCHK(h, hipMemcpyAsync(w.clip_tb.p, m.clip_tb.data(), (size_t)(nk + 1) * nc * 8, hipMemcpyHostToDevice, fa));
         if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(w.clipmax.p, 0, nc * 4, fa));
         PassParams p = base_params(t);
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
@@ -811,12 +846,14 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             p.n_sel = m.sel_off[(size_t)k * (nc + 1) + nc];
             p.vt_begin = chunk_lo(k);
             p.vt_end = (k == nk - 1) ? INT64_MAX : chunk_hi(k);
+            p.clip_t0 = proportional ? static_cast<const int64_t *>(w.clip_tb.p) + (size_t)k * nc : nullptr;
+            p.clip_t1 = proportional ? static_cast<const int64_t *>(w.clip_tb.p) + (size_t)(k + 1) * nc : nullptr;
             if (feed) {      // frame t reads samples [t*hop - 1024, t*hop + 1024)
                 bool any = false;
                 for (int i = 0; i < nc; ++i) {
                     const int ci = pc[i];
                     const int64_t n = sample_offsets[ci + 1] - sample_offsets[ci];
-                    const int64_t fr = std::min(frames[ci], chunk_hi(k));
+                    const int64_t fr = clip_hi(k, i);
                     const int64_t need = (k == nk - 1) ? n : std::min(n, (fr - 1) * (int64_t)t.hop + t.n_fft / 2);
                     int64_t &done = feed->copied[ci];
                     if (need > done) {

@@ -64,6 +64,10 @@ struct PassParams {
     // t_begin .. t_begin + (sel_off[c+1]-sel_off[c]) - 1; the whole pass is sel_off == frame_off, t_begin == 0
     const int64_t *sel_off;      // [n_clips+1]
     int64_t t_begin;
+    // Ragged passes cut every clip into the SAME number of time chunks, each proportional to the clip's length (see
+    // aegis_api.hip): clip c then contributes its frames clip_t0[c] .. clip_t0[c] + (sel_off[c+1]-sel_off[c]) - 1 and its
+    // Viterbi steps [max(1, clip_t0[c]), min(T, clip_t1[c])).  NULL: t_begin / vt_begin / vt_end for every clip.
+    const int64_t *clip_t0, *clip_t1;
     int64_t n_sel;
     // Viterbi step range of this launch: t in [max(1, vt_begin), min(T, vt_end)); state carried in vstate
     int64_t vt_begin, vt_end;

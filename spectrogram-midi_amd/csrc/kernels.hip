@@ -43,7 +43,7 @@ __device__ __forceinline__ int64_t geo_vt_end(const PassParams &p) { return p.ct
 // selected-frame index of this launch -> (clip, frame within clip, frame within pass = workspace row)
 __device__ __forceinline__ void map_frame(const PassParams &p, int64_t fs, int &c, int64_t &t, int64_t &f) {
     c = find_clip(p.sel_off, p.n_clips, fs);
-    t = geo_t_begin(p) + (fs - p.sel_off[c]);
+    t = (p.clip_t0 ? p.clip_t0[c] : geo_t_begin(p)) + (fs - p.sel_off[c]);
     f = p.frame_off[c] + t;
 }
 // frame t of clip c in the output arrays

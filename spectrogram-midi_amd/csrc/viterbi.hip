@@ -78,7 +78,7 @@ __global__ __launch_bounds__(1024) void viterbi_kernel(PassParams p, DevTables t
     const int dlo = max(0, H - b2);
     const int dhi = min(W - 1, B - 1 - b2 + H);
 
-    const int64_t vt_begin = geo_vt_begin(p), vt_end = geo_vt_end(p);
+    const int64_t vt_begin = p.clip_t0 ? p.clip_t0[c] : geo_vt_begin(p), vt_end = p.clip_t0 ? p.clip_t1[c] : geo_vt_end(p);
     if (p.ctl && p.ctl->n_sel == 0) return;                     // graph replay of a push that completed no frame
     const int t_lo = (int)(vt_begin > 1 ? vt_begin : 1);
     const int t_hi = (int)(vt_end < T ? vt_end : T);
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
     const int sidx = (is_low || is_high) ? 2 * PADB + vp * 2 * H + eidx : vp * PADB + b2c + H;
     auto store_value = [&](int buf, double v) { val[buf * PB + sidx] = v; };
 
-    const int64_t vt_begin = geo_vt_begin(p), vt_end = geo_vt_end(p);
+    const int64_t vt_begin = p.clip_t0 ? p.clip_t0[c] : geo_vt_begin(p), vt_end = p.clip_t0 ? p.clip_t1[c] : geo_vt_end(p);
     if (p.ctl && p.ctl->n_sel == 0) return;                     // graph replay of a push that completed no frame
     const int t_lo = (int)(vt_begin > 1 ? vt_begin : 1);
     const int t_hi = (int)(vt_end < T ? vt_end : T);

@@ -328,17 +328,21 @@ def test_time_chunk_pipeline_ragged(monkeypatch):
              signals.polyphonic_clip(7.7, seed=7), signals.guitar_clip(3.0, seed=8)[:100003]]
     ref_h = _lib.Handle()
     ref = ref_h.analyze_batch(clips)
-    for chunk in ("64", "256"):
+    # both cuts of a ragged pass: every clip into the same number of chunks, each proportional to its length (what runs),
+    # and one time axis for all clips (AEGIS_PROPORTIONAL_CHUNKS=0: short clips end in early chunks)
+    for chunk, prop in (("64", "1"), ("64", "0"), ("256", "1"), ("256", "0")):
         monkeypatch.setenv("AEGIS_TIME_CHUNK", chunk)
+        monkeypatch.setenv("AEGIS_PROPORTIONAL_CHUNKS", prop)
         h = _lib.Handle()
         got = h.analyze_batch(clips)
         again = h.analyze_batch(list(reversed(clips)))[::-1]
         for i in range(len(clips)):
             for k in ref[i]:
-                np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"chunk {chunk} clip {i} {k}")
-                np.testing.assert_array_equal(again[i][k], ref[i][k], err_msg=f"chunk {chunk} reversed clip {i} {k}")
+                np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop} clip {i} {k}")
+                np.testing.assert_array_equal(again[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop} reversed clip {i} {k}")
         h.close()
     monkeypatch.delenv("AEGIS_TIME_CHUNK")
+    monkeypatch.delenv("AEGIS_PROPORTIONAL_CHUNKS")
     o = oengine.audio_to_midi(clips[3])
     np.testing.assert_array_equal(ref[3]["voiced_flag"], o["voiced_flag"])
     np.testing.assert_allclose(np.nan_to_num(ref[3]["f0"]), o["f0"], rtol=1e-13)
