@@ -455,27 +455,35 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             if (!want_fft) continue;
 
             // ---- A[k] = FFT(x)[k], B[k] = FFT(b)[k] from Z by symmetry; P = A*B; windowed power from A ----------
-            auto Aof = [&](int k) {                  // k taken modulo 2048: A[-1] = conj(A[1]), A[1025] = conj(A[1023])
-                const double2 zk = z[zsw(k & 2047)], zn = z[zsw((2048 - k) & 2047)];
-                return make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
-            };
+            // A thread owns FIVE CONSECUTIVE bins k = 5 tid .. 5 tid + 4 (205 threads cover 0..1024): the windowed spectrum
+            // needs A[k - 1] and A[k + 1], which are then the thread's own neighbours -- seven (z[k], z[2048 - k]) pairs per
+            // thread and frame instead of fifteen with bins 256 apart.  (Lanes 80 bytes apart: 16 lanes of a ds_read_b128
+            // fall on 16 distinct bank groups.)  k is taken modulo 2048: A[-1] = conj(A[1]), A[1025] = conj(A[1023]).
+            if (tid < 205) {
+                auto zpair = [&](int k, double2 &zk, double2 &zn) { zk = z[zsw(k & 2047)]; zn = z[zsw((2048 - k) & 2047)]; };
+                auto Afrom = [](const double2 &zk, const double2 &zn) { return make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5); };
+                const int k0 = 5 * tid;
+                double2 zk, zn, zk1, zn1;
+                zpair(k0 - 1, zk, zn);
+                double2 Am = Afrom(zk, zn);
+                zpair(k0, zk, zn);
+                double2 A = Afrom(zk, zn);
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int k = tid + r * 256;
-                if (k <= 1024) {
-                    const double2 zk = z[zsw(k)], zn = z[zsw((2048 - k) & 2047)];
-                    const double2 A = make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5);
+                for (int r = 0; r < 5; ++r) {
+                    const int k = k0 + r;
+                    zpair(k + 1, zk1, zn1);
+                    const double2 Ap = Afrom(zk1, zn1);
                     if (want_pyin) {
                         const double2 Bv = make_double2((zk.y + zn.y) * 0.5, (zn.x - zk.x) * 0.5);
                         P[h][r] = c_mul(A, Bv);
                     }
                     if (want_mel) {
-                        const double2 am = Aof(k - 1), ap = Aof(k + 1);
-                        const float re = (float)(0.5 * A.x - 0.25 * (am.x + ap.x));
-                        const float im = (float)(0.5 * A.y - 0.25 * (am.y + ap.y));
+                        const float re = (float)(0.5 * A.x - 0.25 * (Am.x + Ap.x));
+                        const float im = (float)(0.5 * A.y - 0.25 * (Am.y + Ap.y));
                         const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
                         (h == 0 ? pw : pw1)[k] = mag * mag;
                     }
+                    Am = A; A = Ap; zk = zk1; zn = zn1;
                 }
             }
             if (want_mel && h == 1 && tid < 15) pw1[1025 + tid] = 0.0f;      // the last chunks read (zero-weighted) bins past 1024
@@ -533,10 +541,10 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         if (!want_pyin) continue;
 
         // ---- one inverse FFT for both frames: conj(Q), Q = Hermitian extension of P0 + i*P1 ---------------------
+        if (tid < 205) {                         // the thread's own five consecutive bins (see above)
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            const int k = tid + r * 256;
-            if (k <= 1024) {
+            for (int r = 0; r < 5; ++r) {
+                const int k = 5 * tid + r;
                 const double2 u = P[0][r], v = P[1][r];
                 z[zsw(k)] = make_double2(u.x - v.y, -u.y - v.x);                          // conj(P0) - i conj(P1)
                 if (k > 0 && k < 1024) z[zsw(2048 - k)] = make_double2(u.x + v.y, u.y - v.x);   // P0 - i P1
