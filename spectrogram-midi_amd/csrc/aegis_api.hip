@@ -682,7 +682,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // on an otherwise idle chip (512-clip folder: the last 36 of 363 ms); with proportional chunks every launch
         // carries every clip and all of them finish with the last chunk.  The results do not depend on the cut.
         bool proportional = false;
-        if (py && !balanced && nk > 2 && h->proportional_chunks) {
+        // (not for a pass fed from host memory: it is bound by the pageable copies, and a short clip's proportional chunk is a
+        // copy of a few hundred KB -- 512-clip folder, host-inclusive: 496 ms against 466 on one time axis)
+        if (py && !balanced && !feed && nk > 2 && h->proportional_chunks) {
             int64_t minF = maxF;
             for (int i = 0; i < nc; ++i) minF = std::min(minF, frames[pc[i]]);
             proportional = 4 * minF < 3 * maxF;

@@ -340,6 +340,11 @@ def test_time_chunk_pipeline_ragged(monkeypatch):
             for k in ref[i]:
                 np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop} clip {i} {k}")
                 np.testing.assert_array_equal(again[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop} reversed clip {i} {k}")
+        # the device-pointer entry: the one that takes the proportional cut (a pass fed from host memory keeps one time axis)
+        dev = _analyze_on_device(h, clips)
+        for k in ("f0", "voiced_flag", "voiced_prob", "rms", "rake_mask"):
+            want = np.concatenate([np.asarray(ref[i][k]) for i in range(len(clips))])
+            np.testing.assert_array_equal(dev[k].astype(want.dtype), want, err_msg=f"device entry, chunk {chunk}/{prop} {k}")
         h.close()
     monkeypatch.delenv("AEGIS_TIME_CHUNK")
     monkeypatch.delenv("AEGIS_PROPORTIONAL_CHUNKS")
