@@ -19,6 +19,11 @@ AEGIS_HD int zsw(int i) { return i ^ ((i >> 3) & 7); }
 AEGIS_HD double2 c_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 AEGIS_HD double2 c_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 AEGIS_HD double2 c_mul(double2 a, double2 b) { return make_double2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// the same product with two fused multiply-adds (two roundings fewer, four instructions instead of six): the twiddle
+// multiplications of the FFT passes, a quarter of their float64 work
+AEGIS_HD double2 c_mul_f(double2 a, double2 b) {
+    return make_double2(__builtin_fma(a.x, b.x, -(a.y * b.y)), __builtin_fma(a.x, b.y, a.y * b.x));
+}
 AEGIS_HD double2 c_mul_mi(double2 a) { return make_double2(a.y, -a.x); }   // a * (-i)
 
 // forward 4-point DFT, natural order in and out
@@ -74,7 +79,7 @@ AEGIS_HD void fft8_read8(const double2 *z, int j, double2 (&v)[8]) {
 template <int NS>
 AEGIS_HD void fft8_pass_write(double2 *z, int j, double2 (&v)[8], const double2 (&w)[7]) {
 #pragma unroll
-    for (int q = 1; q < 8; ++q) v[q] = c_mul(v[q], w[q - 1]);
+    for (int q = 1; q < 8; ++q) v[q] = c_mul_f(v[q], w[q - 1]);
     dft8(v);
     const int k = j & (NS - 1);
     const int j0 = ((j - k) << 3) + k;
@@ -88,7 +93,7 @@ AEGIS_HD void fft8_pass4(double2 *z, int j, const Fft8Tw &w) {
     for (int b = 0; b < 2; ++b) {
         const int jj = j + 256 * b;
         double2 a0 = z[zsw(jj)], a1 = z[zsw(jj + 512)], a2 = z[zsw(jj + 1024)], a3 = z[zsw(jj + 1536)];
-        a1 = c_mul(a1, w.p4[b][0]); a2 = c_mul(a2, w.p4[b][1]); a3 = c_mul(a3, w.p4[b][2]);
+        a1 = c_mul_f(a1, w.p4[b][0]); a2 = c_mul_f(a2, w.p4[b][1]); a3 = c_mul_f(a3, w.p4[b][2]);
         dft4(a0, a1, a2, a3);
         z[zsw(jj)] = a0; z[zsw(jj + 512)] = a1; z[zsw(jj + 1024)] = a2; z[zsw(jj + 1536)] = a3;
     }
