@@ -99,4 +99,23 @@ AEGIS_HD void fft8_pass4(double2 *z, int j, const Fft8Tw &w) {
     }
 }
 
+// The last pass of the INVERSE transform of the frame kernel: only the outputs 1024 .. 1024 + max_lag are ever read
+// (the autocorrelation at lags 0..max_lag of the two packed frames), i.e. output 2 of every butterfly and output 3 of the
+// butterflies jj <= max_lag - 512.  Same values as fft8_pass4 at those positions; the other three quarters of the
+// outputs are neither computed nor stored.
+AEGIS_HD void fft8_pass4_lags(double2 *z, int j, const Fft8Tw &w, int max_lag) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int jj = j + 256 * b;
+        double2 a0 = z[zsw(jj)], a1 = z[zsw(jj + 512)], a2 = z[zsw(jj + 1024)], a3 = z[zsw(jj + 1536)];
+        a1 = c_mul_f(a1, w.p4[b][0]); a2 = c_mul_f(a2, w.p4[b][1]); a3 = c_mul_f(a3, w.p4[b][2]);
+        const double2 s0 = c_add(a0, a2), s2 = c_add(a1, a3);
+        z[zsw(jj + 1024)] = c_sub(s0, s2);
+        if (jj + 512 <= max_lag) {
+            const double2 s1 = c_sub(a0, a2), s3 = c_mul_mi(c_sub(a1, a3));
+            z[zsw(jj + 1536)] = c_sub(s1, s3);
+        }
+    }
+}
+
 }  // namespace aegis

@@ -565,7 +565,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             __syncthreads();
             fft8_pass_write<64>(z, tid, v, twr.p3);
             __syncthreads();
-            fft8_pass4(z, tid, twr);
+            fft8_pass4_lags(z, tid, twr, mp);          // only the lags the difference function reads
             __syncthreads();
         }
         FRM_TICK(5)
