@@ -461,7 +461,10 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             // fall on 16 distinct bank groups.)  k is taken modulo 2048: A[-1] = conj(A[1]), A[1025] = conj(A[1023]).
             if (tid < 205) {
                 auto zpair = [&](int k, double2 &zk, double2 &zn) { zk = z[zsw(k & 2047)]; zn = z[zsw((2048 - k) & 2047)]; };
-                auto Afrom = [](const double2 &zk, const double2 &zn) { return make_double2((zk.x + zn.x) * 0.5, (zk.y - zn.y) * 0.5); };
+                // A2 = 2 A and B2 = 2 B: the halves are folded into the powers of two applied later (P = A B arrives as 4 P in the
+                // inverse transform, whose outputs are scaled by 1/8192 instead of 1/2048; the windowed spectrum is
+                // A/2 - (A- + A+)/4 = (2 A2 - (A2- + A2+)) / 8) -- exact scalings, every value bit-identical
+                auto Afrom = [](const double2 &zk, const double2 &zn) { return make_double2(zk.x + zn.x, zk.y - zn.y); };
                 const int k0 = 5 * tid;
                 double2 zk, zn, zk1, zn1;
                 zpair(k0 - 1, zk, zn);
@@ -474,12 +477,12 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                     zpair(k + 1, zk1, zn1);
                     const double2 Ap = Afrom(zk1, zn1);
                     if (want_pyin) {
-                        const double2 Bv = make_double2((zk.y + zn.y) * 0.5, (zn.x - zk.x) * 0.5);
+                        const double2 Bv = make_double2(zk.y + zn.y, zn.x - zk.x);
                         P[h][r] = c_mul(A, Bv);
                     }
                     if (want_mel) {
-                        const float re = (float)(0.5 * A.x - 0.25 * (Am.x + Ap.x));
-                        const float im = (float)(0.5 * A.y - 0.25 * (Am.y + Ap.y));
+                        const float re = (float)(0.125 * (2.0 * A.x - (Am.x + Ap.x)));
+                        const float im = (float)(0.125 * (2.0 * A.y - (Am.y + Ap.y)));
                         const float mag = (float)sqrt((double)re * (double)re + (double)im * (double)im);  // npy_hypotf
                         (h == 0 ? pw : pw1)[k] = mag * mag;
                     }
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
                 const int tau = tid + 256 * u;
                 if (tau <= mp) {
                     const double2 zz = z[zsw(1024 + tau)];
-                    double a0 = zz.x * (1.0 / 2048.0), a1 = -zz.y * (1.0 / 2048.0);
+                    double a0 = zz.x * (1.0 / 8192.0), a1 = -zz.y * (1.0 / 8192.0);      // 1/2048 of the transform, 1/4 of P (see A2, B2)
                     if (fabs(a0) < 1e-6) a0 = 0.0;
                     if (fabs(a1) < 1e-6) a1 = 0.0;
                     if (flive[0]) d0[tau] = (double)es[0][u] - 2.0 * a0;
@@ -613,7 +616,7 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
             double *__restrict__ drow = p.dfn + fidx[h] * (int64_t)p.lag_stride;
             for (int tau = tid; tau <= mp; tau += 256) {
                 const double2 zz = z[zsw(1024 + tau)];
-                double a = (h == 0 ? zz.x : -zz.y) * (1.0 / 2048.0);
+                double a = (h == 0 ? zz.x : -zz.y) * (1.0 / 8192.0);
                 if (fabs(a) < 1e-6) a = 0.0;
                 float e = row[tau];
                 if (fabsf(e) < 1e-6f) e = 0.0f;
