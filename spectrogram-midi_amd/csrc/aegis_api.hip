@@ -52,6 +52,7 @@ struct aegis_handle {
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
     int chunk_growth_pct = 125, ramp_k = 4;   // AEGIS_CHUNK_GROWTH, AEGIS_RAMP_K (first chunks alternating over two frame streams)
+    int dense_mode = -1;                      // AEGIS_DENSE: -1 (unset) = passes of >= 256 clips, 0 = never, 1 = every unbalanced pass
     bool proportional_chunks = true;          // ragged unbalanced passes cut every clip into the same number of chunks (AEGIS_PROPORTIONAL_CHUNKS=0: one time axis)
     int64_t feed_chunk = 1024;                // chunk size of balanced passes fed from host memory (AEGIS_FEED_CHUNK)
     int64_t balanced_chunk = 384;             // chunk size of balanced passes (AEGIS_BALANCED_CHUNK, 0 = never balanced)
@@ -296,6 +297,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
+    if (const char *e = std::getenv("AEGIS_DENSE")) h->dense_mode = e[0] == '0' ? 0 : 1;
     if (const char *e = std::getenv("AEGIS_PROPORTIONAL_CHUNKS")) h->proportional_chunks = e[0] != '0';
     if (const char *e = std::getenv("AEGIS_FEED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= kViterbiChunk && v % kViterbiChunk == 0) h->feed_chunk = v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_ENDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->balanced_ends = v; }
@@ -681,6 +683,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // the short clips are done after a few chunks and the last launches hold only the long clips' Viterbi workgroups
         // on an otherwise idle chip (512-clip folder: the last 36 of 363 ms); with proportional chunks every launch
         // carries every clip and all of them finish with the last chunk.  The results do not depend on the cut.
+        // Throughput passes (a Viterbi workgroup for every CU and more): the register-capped Viterbi build and four-wave
+        // observation workgroups (viterbi.hip); AEGIS_DENSE=0 turns it off, =1 forces it for every unbalanced pass (tests).
+        const bool dense = py && !balanced && viterbi_band_applies(base_params(t), h->dt) && t.half_width == 25 &&
+                           (h->dense_mode == 1 || (h->dense_mode < 0 && nc >= 256));
         bool proportional = false;
         // (not for a pass fed from host memory: it is bound by the pageable copies, and a short clip's proportional chunk is a
         // copy of a few hundred KB -- 512-clip folder, host-inclusive: 496 ms against 466 on one time axis)
@@ -848,6 +854,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             p.n_sel = m.sel_off[(size_t)k * (nc + 1) + nc];
             p.vt_begin = chunk_lo(k);
             p.vt_end = (k == nk - 1) ? INT64_MAX : chunk_hi(k);
+            p.dense = dense ? 1 : 0;
             p.clip_t0 = proportional ? static_cast<const int64_t *>(w.clip_tb.p) + (size_t)k * nc : nullptr;
             p.clip_t1 = proportional ? static_cast<const int64_t *>(w.clip_tb.p) + (size_t)(k + 1) * nc : nullptr;
             if (feed) {      // frame t reads samples [t*hop - 1024, t*hop + 1024)

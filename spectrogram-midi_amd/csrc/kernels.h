@@ -68,6 +68,8 @@ struct PassParams {
     // aegis_api.hip): clip c then contributes its frames clip_t0[c] .. clip_t0[c] + (sel_off[c+1]-sel_off[c]) - 1 and its
     // Viterbi steps [max(1, clip_t0[c]), min(T, clip_t1[c])).  NULL: t_begin / vt_begin / vt_end for every clip.
     const int64_t *clip_t0, *clip_t1;
+    int32_t dense;               // throughput pass (a Viterbi workgroup on every CU): the 96-register Viterbi build and four-wave
+                                 // observation workgroups, which share its CUs (viterbi.hip, launch_pyin_obs)
     int64_t n_sel;
     // Viterbi step range of this launch: t in [max(1, vt_begin), min(T, vt_end)); state carried in vstate
     int64_t vt_begin, vt_end;

@@ -1351,7 +1351,8 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     const int UN = (std::max(DN, 2 * KM + (4 * KM + 7) / 8) + 1) & ~1, TN = (2 * (KM + 1) + 101 + 1) & ~1;
     // eight waves share one copy of the tables (two such workgroups per CU); small launches (streaming pushes) get a wave
     // per frame and one frame per wave
-    int waves = (int)std::min<int64_t>(8, p.n_sel);
+    // (a dense pass -- PassParams::dense -- takes four-wave workgroups: one wave per SIMD fits beside a Viterbi workgroup)
+    int waves = (int)std::min<int64_t>(p.dense ? 4 : 8, p.n_sel);
     while (waves > 1 && (size_t)(TN + waves * (YN + UN)) * 8 + 1024 > 80 * 1024) --waves;
     const int fpw = p.n_sel >= 4096 ? 4 : 1;
     const size_t lds = (size_t)(TN + waves * (YN + UN)) * 8;

@@ -330,24 +330,28 @@ def test_time_chunk_pipeline_ragged(monkeypatch):
     ref = ref_h.analyze_batch(clips)
     # both cuts of a ragged pass: every clip into the same number of chunks, each proportional to its length (what runs),
     # and one time axis for all clips (AEGIS_PROPORTIONAL_CHUNKS=0: short clips end in early chunks)
-    for chunk, prop in (("64", "1"), ("64", "0"), ("256", "1"), ("256", "0")):
+    # ... and the two builds of the band Viterbi: AEGIS_DENSE=1 forces the register-capped one with four-wave observation
+    # workgroups (what passes of >= 256 clips take) on this small batch
+    for chunk, prop, dense in (("64", "1", "0"), ("64", "0", "0"), ("256", "1", "0"), ("256", "0", "0"), ("64", "1", "1"), ("256", "0", "1")):
         monkeypatch.setenv("AEGIS_TIME_CHUNK", chunk)
         monkeypatch.setenv("AEGIS_PROPORTIONAL_CHUNKS", prop)
+        monkeypatch.setenv("AEGIS_DENSE", dense)
         h = _lib.Handle()
         got = h.analyze_batch(clips)
         again = h.analyze_batch(list(reversed(clips)))[::-1]
         for i in range(len(clips)):
             for k in ref[i]:
-                np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop} clip {i} {k}")
-                np.testing.assert_array_equal(again[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop} reversed clip {i} {k}")
+                np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop}/{dense} clip {i} {k}")
+                np.testing.assert_array_equal(again[i][k], ref[i][k], err_msg=f"chunk {chunk}/{prop}/{dense} reversed clip {i} {k}")
         # the device-pointer entry: the one that takes the proportional cut (a pass fed from host memory keeps one time axis)
         dev = _analyze_on_device(h, clips)
         for k in ("f0", "voiced_flag", "voiced_prob", "rms", "rake_mask"):
             want = np.concatenate([np.asarray(ref[i][k]) for i in range(len(clips))])
-            np.testing.assert_array_equal(dev[k].astype(want.dtype), want, err_msg=f"device entry, chunk {chunk}/{prop} {k}")
+            np.testing.assert_array_equal(dev[k].astype(want.dtype), want, err_msg=f"device entry, chunk {chunk}/{prop}/{dense} {k}")
         h.close()
     monkeypatch.delenv("AEGIS_TIME_CHUNK")
     monkeypatch.delenv("AEGIS_PROPORTIONAL_CHUNKS")
+    monkeypatch.delenv("AEGIS_DENSE")
     o = oengine.audio_to_midi(clips[3])
     np.testing.assert_array_equal(ref[3]["voiced_flag"], o["voiced_flag"])
     np.testing.assert_allclose(np.nan_to_num(ref[3]["f0"]), o["f0"], rtol=1e-13)
