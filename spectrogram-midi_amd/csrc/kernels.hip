@@ -1354,7 +1354,7 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s) {
     // (a dense pass -- PassParams::dense -- takes four-wave workgroups: one wave per SIMD fits beside a Viterbi workgroup)
     int waves = (int)std::min<int64_t>(p.dense ? 4 : 8, p.n_sel);
     while (waves > 1 && (size_t)(TN + waves * (YN + UN)) * 8 + 1024 > 80 * 1024) --waves;
-    const int fpw = p.n_sel >= 4096 ? 4 : 1;
+    const int fpw = p.n_sel >= 4096 ? (p.dense ? 8 : 4) : 1;     // (dense: half the waves per workgroup, twice the frames per wave)
     const size_t lds = (size_t)(TN + waves * (YN + UN)) * 8;
     const int64_t per_wg = (int64_t)waves * fpw;
     hipLaunchKernelGGL(pyin_obs_kernel, dim3((unsigned)((p.n_sel + per_wg - 1) / per_wg)), dim3(64 * waves), lds, s, p, t, fpw);
