@@ -3,7 +3,7 @@
 import collections, csv, json, sys
 
 NAMES = {"frame_yin_kernel": "frame", "pyin_obs_kernel": "pyin_obs",
-         "viterbi_band_kernel": "viterbi", "viterbi_kernel": "viterbi", "decode_kernel": "finalize",
+         "viterbi_band_kernel": "viterbi", "viterbi_band_dense_kernel": "viterbi", "viterbi_kernel": "viterbi", "decode_kernel": "finalize",
          "db_rake_kernel": "finalize", "rake_runs_kernel": "finalize"}
 
 

@@ -3,7 +3,7 @@
 python3 tools/summarize_sq.py <steps_total> <out.json> <csv> [<csv> ...]"""
 import collections, csv, json, sys
 
-NAMES = {"frame_yin_kernel": "frame", "pyin_obs_kernel": "pyin_obs", "viterbi_band_kernel": "viterbi",
+NAMES = {"frame_yin_kernel": "frame", "pyin_obs_kernel": "pyin_obs", "viterbi_band_kernel": "viterbi", "viterbi_band_dense_kernel": "viterbi",
          "viterbi_kernel": "viterbi", "db_rake_kernel": "db_rake"}
 
 
