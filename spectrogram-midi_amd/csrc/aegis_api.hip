@@ -7,6 +7,7 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
@@ -95,6 +96,7 @@ struct aegis_handle {
     std::vector<PassMeta> metas;
     // last pass geometry for aegis_debug_fetch
     int64_t last_frames = 0;
+    int last_passes = 0, last_chunks = 0, last_dense = 0, last_proportional = 0, last_balanced = 0, last_persistent = 0;   // of the last call (its last pass)
     // profiling
     bool profiling = false;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> events;
@@ -374,31 +376,43 @@ void aegis_destroy(aegis_handle *h) {
 
 static void destroy_now(aegis_handle *h) noexcept {
     if (h->device < 0) { delete h; return; }
+    // AEGIS_TRACE_DESTROY=1: one line on stderr before every step that can block (which call a teardown sat in)
+    const bool trace = std::getenv("AEGIS_TRACE_DESTROY") != nullptr;
+    auto T = [&](const char *what) { if (trace) { std::fprintf(stderr, "[aegis destroy] %s\n", what); std::fflush(stderr); } };
+    T("hipSetDevice");
     (void)hipSetDevice(h->device);
     for (auto &ss : h->split)
         for (hipStream_t q : {ss.frame_a, ss.frame_b, ss.viterbi})
-            if (q) { (void)hipStreamSynchronize(q); (void)hipStreamDestroy(q); }
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
-    if (h->stream2) (void)hipStreamSynchronize(h->stream2);
-    if (h->stream3) (void)hipStreamSynchronize(h->stream3);
-    if (h->stream4) (void)hipStreamSynchronize(h->stream4);
+            if (q) { T("sync masked stream"); (void)hipStreamSynchronize(q); T("destroy masked stream"); (void)hipStreamDestroy(q); }
+    T("sync stream"); if (h->stream) (void)hipStreamSynchronize(h->stream);
+    T("sync stream2"); if (h->stream2) (void)hipStreamSynchronize(h->stream2);
+    T("sync stream3"); if (h->stream3) (void)hipStreamSynchronize(h->stream3);
+    T("sync stream4"); if (h->stream4) (void)hipStreamSynchronize(h->stream4);
+    T("events");
+    for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); }
+    h->events.clear();
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
+    T("free tables");
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
+    T("free workspaces");
     for (auto &w : h->work)
         for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.obs_seg, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
                           &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
                           &w.vstate, &w.chunk_lo, &w.chunk_flag, &w.clip_tb})
             free_buf(*b);
+    T("free staging");
     for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->finite_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
                       &h->t_i8, &h->t_i64a, &h->t_i64b, &h->t_pa, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb, &h->io_bin, &h->io_colmean})
         free_buf(*b);
+    T("destroy streams");
     if (h->stream) (void)hipStreamDestroy(h->stream);
     if (h->stream2) (void)hipStreamDestroy(h->stream2);
     if (h->stream3) (void)hipStreamDestroy(h->stream3);
     if (h->stream4) (void)hipStreamDestroy(h->stream4);
     if (h->copy_event) (void)hipEventDestroy(h->copy_event);
+    T("done");
     delete h;
 }
 
@@ -920,10 +934,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         done_recorded[pass_index & 1] = true;
         HIPCHK(h, hipGetLastError());
         h->last_frames = fp;
+        h->last_chunks = nk; h->last_dense = dense ? 1 : 0; h->last_proportional = proportional ? 1 : 0;
+        h->last_balanced = balanced ? 1 : 0; h->last_persistent = persistent ? 1 : 0;
         h->last_work = pass_index & 1;
         first = last;
         ++pass_index;
     }
+    h->last_passes = pass_index;
     // the caller's stream continues after everything enqueued above
     for (int q = 0; q < 2; ++q)
         if (done_recorded[q]) HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[EV_DONE0 + q], 0));
@@ -1717,6 +1734,12 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "yin_stride") return h->yin_stride;
     if (n == "obs_stride") return h->obs_stride;
     if (n == "last_frames") return h->last_frames;
+    if (n == "last_passes") return h->last_passes;
+    if (n == "last_chunks") return h->last_chunks;
+    if (n == "last_dense") return h->last_dense;
+    if (n == "last_proportional") return h->last_proportional;
+    if (n == "last_balanced") return h->last_balanced;
+    if (n == "last_persistent") return h->last_persistent;
     if (n == "pyin_init") return t.pyin_init;
     return AEGIS_ERR_INVALID;
     } catch (...) { return abi_fail(const_cast<aegis_handle *>(h)); }

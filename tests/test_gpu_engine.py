@@ -528,6 +528,111 @@ def test_persistent_viterbi_gives_up(monkeypatch):
     h.close(); ref_h.close()
 
 
+def _per_clip(dev, clips, hop=512):
+    """Concatenated device-entry arrays -> per-clip dicts with the raw_data names and dtypes."""
+    out, o = [], 0
+    for c in clips:
+        F = 1 + len(c) // hop
+        out.append({"f0": dev["f0"][o:o + F], "voiced_flag": dev["voiced_flag"][o:o + F].astype(bool),
+                    "voiced_probs": dev["voiced_prob"][o:o + F], "rms": dev["rms"][o:o + F],
+                    "rake_mask": dev["rake_mask"][o:o + F].astype(bool)})
+        o += F
+    assert o == len(dev["f0"])
+    return out
+
+
+def _check_throughput_pass(monkeypatch, clips, solo, oracle, tag):
+    """What the two >= 256-clip tests below share.  `clips` through the device-pointer entry on a default handle (pass
+    size from the free device memory, auto-dense Viterbi build + four-wave observation workgroups, proportional chunks
+    when ragged): ONE pass, the dense build, no fallback of the single launch; frame counts; f0 NaN exactly where
+    unvoiced and on the pitch grid elsewhere; the clips `solo` bit-identical to the same clip analysed alone; the clips
+    `oracle` equal to oracle.engine.audio_to_midi; and the whole batch bit-identical with AEGIS_DENSE=0 (128-register
+    build, eight-wave observation workgroups) and with AEGIS_DENSE=0 AEGIS_PROPORTIONAL_CHUNKS=0 (one time axis)."""
+    ragged = len({len(c) for c in clips}) > 1
+    h = _lib.Handle()
+    dev = _analyze_on_device(h, clips)
+    assert h.param("last_passes") == 1 and h.param("last_dense") == 1, tag
+    assert h.param("last_proportional") == (1 if ragged else 0) and h.param("last_chunks") > 2, tag
+    assert int(h.debug_fetch("persistent_fallbacks")[0]) == 0
+    grid = h.table("freqs")
+    h.close()
+    got = _per_clip(dev, clips)
+    voiced = dev["voiced_flag"].astype(bool)
+    assert np.array_equal(np.isnan(dev["f0"]), ~voiced), tag
+    assert np.isin(dev["f0"][voiced], grid).all(), tag
+    assert 0.05 < voiced.mean() < 0.98, tag
+    assert (dev["voiced_prob"] >= 0).all() and (dev["voiced_prob"] <= 1).all() and (dev["rms"] >= 0).all(), tag
+    for env in ({"AEGIS_DENSE": "0"}, {"AEGIS_DENSE": "0", "AEGIS_PROPORTIONAL_CHUNKS": "0"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = _lib.Handle()
+        other = _analyze_on_device(h, clips)
+        assert h.param("last_passes") == 1 and h.param("last_dense") == 0 and int(h.debug_fetch("persistent_fallbacks")[0]) == 0
+        assert h.param("last_proportional") == (1 if (ragged and len(env) == 1) else 0)
+        h.close()
+        for k in dev:
+            np.testing.assert_array_equal(other[k], dev[k], err_msg=f"{tag}: {env} {k}")
+        for k in env:
+            monkeypatch.delenv(k)
+    h = _lib.Handle()
+    for i in solo:
+        alone = h.analyze_batch([clips[i]], want_sdb=False)[0]
+        for k, name in (("f0", "f0"), ("voiced_flag", "voiced_flag"), ("voiced_prob", "voiced_probs"), ("rms", "rms"), ("rake_mask", "rake_mask")):
+            np.testing.assert_array_equal(got[i][name], alone[k], err_msg=f"{tag}: clip {i} alone, {k}")
+    h.close()
+    for i in oracle:
+        ref = oengine.audio_to_midi(clips[i])
+        g = dict(got[i], f0=np.nan_to_num(got[i]["f0"]))
+        assert_raw_equal(g, ref, f"{tag}: clip {i} vs oracle")
+
+
+def test_folder_512_clips_one_dense_pass(monkeypatch):
+    """BASELINE.json configs[3] at the size the driver's N = 1 bench line runs (bench.py --config folder: 512 clips,
+    durations U(30, 330) s as folder_audio_collector.py:113 keeps them, 1/8 polyphonic, 1/8 noisy; 97 010 audio-s,
+    8.36 M frames): one pass sized from the free device memory, the register-capped Viterbi build beside four-wave
+    observation workgroups of eight frames per wave, proportional chunks -- the path no smaller test reaches."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    durations = bench.folder_durations(512)
+    clips = bench.make_folder_clips(range(512), durations)
+    assert sum(1 + len(c) // 512 for c in clips) == 8356000
+    order = np.argsort(durations)
+    poly = [i for i in order if i % 8 == 6]
+    noisy = [i for i in order if i % 8 == 7]
+    solo = sorted({int(order[0]), int(order[-1]), int(poly[len(poly) // 2]), int(noisy[len(noisy) // 2]), 0, 511})
+    oracle = [int(order[0]), int(poly[0]), int(noisy[0])]
+    assert all(durations[i] <= 60.0 for i in oracle)
+    _check_throughput_pass(monkeypatch, clips, solo, oracle, "folder")
+
+
+def test_256_clips_of_180_s_one_dense_pass(monkeypatch):
+    """The other >= 256-clip regime: 256 x 180 s (uniform lengths: no proportional cut, 3.97 M frames)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    clips = bench.make_clips(256, 180.0, seed0=1)
+    _check_throughput_pass(monkeypatch, clips, [0, 9, 130, 255], [], "256 x 180 s")
+
+
+def test_dense_pass_of_short_ragged_clips(monkeypatch):
+    """256 clips of 5..60 s (one empty, one shorter than a hop) under default chunking: every chunk selects >= 4096 frames,
+    so the observation kernel runs eight frames per wave on four-wave workgroups beside the register-capped Viterbi build
+    (what a dense pass launches), on clips short enough for the oracle to check several of them."""
+    rng = np.random.default_rng(11)
+    base = [signals.guitar_clip(60.0, seed=51), signals.polyphonic_clip(60.0, seed=52), signals.guitar_clip(60.0, seed=53, noise_dbfs=-12.0)]
+    clips = []
+    for i in range(256):
+        b = base[i % 3]
+        n = int(rng.uniform(5.0, 60.0) * 44100)
+        clips.append(np.ascontiguousarray(np.roll(b, -int(rng.integers(0, len(b))))[:n] * np.float32(rng.uniform(0.5, 1.0)), dtype=np.float32))
+    clips[17] = np.zeros(0, np.float32)
+    clips[18] = clips[18][:300]
+    lens = np.array([len(c) for c in clips])
+    short = [int(i) for i in np.argsort(lens)[2:5]]
+    _check_throughput_pass(monkeypatch, clips, [17, 18, 0, 255, int(np.argmax(lens))], short + [18], "256 short ragged clips")
+
+
 def test_graft_entry_smoke():
     """The driver's smoke() hook itself: one small analyze on cuda:0 checked against the oracle."""
     import __graft_entry__ as g
