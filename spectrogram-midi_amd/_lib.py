@@ -14,6 +14,7 @@ OPT_CHECK_FINITE, OPT_F0_ZERO = 0x10, 0x20
  TREND_KALMAN, TREND_HOLT, TREND_CONSENSUS, TREND_PITCH_ANALYSIS) = range(1, 13)
 OK, ERR_INVALID, ERR_NOMEM, ERR_DEVICE, ERR_UNSUPPORTED = 0, -22, -12, -5, -95
 PYIN_INIT_UNVOICED, PYIN_INIT_UNIFORM = 0, 1      # aegis_config.pyin_init
+ABI_VERSION = 2                                   # include/aegis_hip.h AEGIS_ABI_VERSION: the layout Config / Outputs below assume
 _PYIN_INIT = {"unvoiced": 0, "uniform": 1, 0: 0, 1: 1}
 
 
@@ -58,6 +59,13 @@ def load():
             "__graft_entry__.build()).  There is no CPU fallback for the analyze path.")
     lib = C.CDLL(LIB_PATH)
     lib.aegis_abi_version.restype = C.c_int
+    got = int(lib.aegis_abi_version())
+    if got != ABI_VERSION:
+        # aegis_outputs / aegis_config carry no size field: a library of another ABI would read this module's structs at
+        # the wrong offsets and write device or host memory through stale pointers (AEGIS_HIP_LIB is routinely pointed at
+        # other builds)
+        raise ImportError(f"{LIB_PATH} has ABI version {got}, this binding was written for {ABI_VERSION} "
+                          "(include/aegis_hip.h AEGIS_ABI_VERSION): rebuild the library or update the binding")
     lib.aegis_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     lib.aegis_create.restype = C.c_int
     lib.aegis_destroy.argtypes = [C.c_void_p]

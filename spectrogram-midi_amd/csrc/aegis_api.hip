@@ -381,9 +381,19 @@ static void destroy_now(aegis_handle *h) noexcept {
     auto T = [&](const char *what) { if (trace) { std::fprintf(stderr, "[aegis destroy] %s\n", what); std::fflush(stderr); } };
     T("hipSetDevice");
     (void)hipSetDevice(h->device);
+    const char *exp_ = std::getenv("AEGIS_DESTROY_EXPERIMENT");       // temporary: which teardown order does not hang
+    const int ex = exp_ ? std::atoi(exp_) : 0;
+    if (ex == 1) { T("device sync"); (void)hipDeviceSynchronize(); }
+    if (ex == 3) {      // plain streams first
+        T("plain streams first");
+        for (hipStream_t *q : {&h->stream, &h->stream2, &h->stream3, &h->stream4}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+    }
+    if (ex == 4 && h->copy_event) { T("copy event first"); (void)hipEventDestroy(h->copy_event); h->copy_event = nullptr;
+        for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
+        h->sync_events.clear(); }
     for (auto &ss : h->split)
         for (hipStream_t q : {ss.frame_a, ss.frame_b, ss.viterbi})
-            if (q) { T("sync masked stream"); (void)hipStreamSynchronize(q); T("destroy masked stream"); (void)hipStreamDestroy(q); }
+            if (q) { T("sync masked stream"); (void)hipStreamSynchronize(q); if (ex == 2) continue; T("destroy masked stream"); (void)hipStreamDestroy(q); }
     T("sync stream"); if (h->stream) (void)hipStreamSynchronize(h->stream);
     T("sync stream2"); if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     T("sync stream3"); if (h->stream3) (void)hipStreamSynchronize(h->stream3);
@@ -553,6 +563,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     if (stages & AEGIS_STAGE_RAKE) stages |= AEGIS_STAGE_MEL;
     const uint32_t opts = stages & (AEGIS_OPT_CHECK_FINITE | AEGIS_OPT_F0_ZERO);
     stages &= AEGIS_STAGE_ALL;
+    if ((opts & AEGIS_OPT_CHECK_FINITE) && sync == 0) {      // the verdict is read after a synchronisation: nobody would read it
+        h->err = "AEGIS_OPT_CHECK_FINITE needs sync != 0 (the verdict is reported by the call that synchronises)";
+        return AEGIS_ERR_INVALID;
+    }
     const Tables &t = h->tab;
     if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
     HIPCHK(h, hipSetDevice(h->device));

@@ -1003,7 +1003,7 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                         const double period = (double)(p.min_period + i) + shift;
                         const double f0c = (double)p.sr / period;
                         double r = rint(120.0 * log2(f0c / p.fmin));
-                        r = r < 0.0 ? 0.0 : (r > (double)B ? (double)B : r);
+                        r = !(r >= 0.0) ? 0.0 : (r > (double)B ? (double)B : r);      // NaN-safe (np.clip would keep NaN; no finite input gets here with one)
                         bin = (int)r;
                     }
                     tp[k] = pr;

@@ -63,7 +63,10 @@ class AegisFinancialEngine:
         """analyze_array for a folder of decoded clips: ONE ragged GPU analysis batch (the guitar filters read the three
         column means of the dB image the library computes beside it, so the image itself never leaves the GPU), ONE fused
         pitch-analysis call and ONE ghost-note RSI call for all clips (midi_logic_financial.get_midi_events_financial_batch).
-        Element i is what analyze_array(clips[i], **kwargs) returns."""
+        Element i is what analyze_array(clips[i], **kwargs) returns.  A clip too short for the trend filters (fewer than 10
+        frames: analyze_array raises IndexError, as the reference does) stays out of the fused calls: with
+        return_exceptions=True its element is that exception, otherwise the exception is raised after all other clips have
+        been processed, the full result list attached as `.results`."""
         clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
         if not clips:
             return []
@@ -83,11 +86,11 @@ class AegisFinancialEngine:
                 voiced = g["voiced"] & ~g["mute_mask"]
             items.append({"rake_mask": rake, "f0": f0, "voiced_flag": voiced, "active_probs": r["voiced_prob"], "rms": r["rms"]})
         passthrough = {k: v for k, v in kwargs.items()
-                       if k not in ("confidence_threshold", "rake_sensitivity", "use_financial")}
+                       if k not in ("confidence_threshold", "rake_sensitivity", "use_financial", "return_exceptions")}
         return get_midi_events_financial_batch(items, self.sr, self.hop_length,
                                                confidence_threshold=kwargs.get("confidence_threshold", None),
                                                use_financial=kwargs.get("use_financial", True), verbose=self.verbose,
-                                               **passthrough)
+                                               return_exceptions=kwargs.get("return_exceptions", False), **passthrough)
 
     def render_midi(self, events):
         """aegis_engine_financial.py:190-245: track_name metas, note_on at the start tick, note_off after

@@ -229,25 +229,44 @@ def get_midi_events_financial(rake_mask, f0, voiced_flag, active_probs, rms, sr,
     return _harmonic_stage(events, thr, sr, hop_length, say, kwargs)
 
 
-def get_midi_events_financial_batch(clips, sr, hop_length, confidence_threshold=None, verbose=False, **kwargs):
+def get_midi_events_financial_batch(clips, sr, hop_length, confidence_threshold=None, verbose=False, return_exceptions=False,
+                                    **kwargs):
     """get_midi_events_financial for several clips (each a dict with rake_mask, f0, voiced_flag, active_probs, rms):
     ONE fused pitch-analysis call over all the pitch tracks (FinancialPitchAnalyzer.analyze_pitch_financial_batch) and
     ONE RSI call over all the ghost-note density tracks instead of eight library calls per clip; the per-note logic is
-    the single-clip function's.  -> list of event lists."""
+    the single-clip function's.  -> list of event lists.
+
+    A pitch track shorter than the Bollinger window (10 frames: an empty or sub-0.25 s file) makes the single-clip
+    function raise IndexError, as the reference does (financial_analysis.py:113-146 through np.convolve).  Such clips stay out
+    of the fused calls, so one tiny file in a folder cannot lose the other clips' results: with return_exceptions=True
+    their element is the exception the single-clip call would have raised, otherwise it is raised once every other clip
+    has been processed -- with the complete result list attached as `.results`."""
     say = print if verbose else (lambda *a, **k: None)
     use_financial = kwargs.get("use_financial", True)
-    analyses = [None] * len(clips)
-    if use_financial and clips:
-        an = FinancialPitchAnalyzer(sr=sr, hop_length=hop_length)
-        tracks = [np.where(np.asarray(c["voiced_flag"], bool), np.asarray(c["f0"], np.float64), np.nan) for c in clips]
-        analyses = an.analyze_pitch_financial_batch(tracks, labels=False)
-    staged = [_financial_notes(c["rake_mask"], c["f0"], c["voiced_flag"], c["active_probs"], c["rms"], sr, hop_length,
-                               confidence_threshold, say, a, kwargs) for c, a in zip(clips, analyses)]
-    lists = [ev for ev, _, _ in staged]
+    errors = {}
     if use_financial:
-        need = [i for i, ev in enumerate(lists) if len(ev) > 10]
+        for i, c in enumerate(clips):
+            if len(c["f0"]) < 10:
+                errors[i] = IndexError(f"clip {i}: series of {len(c['f0'])} samples is shorter than the window 10")
+    live = [i for i in range(len(clips)) if i not in errors]
+    analyses = {i: None for i in live}
+    if use_financial and live:
+        an = FinancialPitchAnalyzer(sr=sr, hop_length=hop_length)
+        tracks = [np.where(np.asarray(clips[i]["voiced_flag"], bool), np.asarray(clips[i]["f0"], np.float64), np.nan) for i in live]
+        analyses = dict(zip(live, an.analyze_pitch_financial_batch(tracks, labels=False)))
+    staged = {i: _financial_notes(clips[i]["rake_mask"], clips[i]["f0"], clips[i]["voiced_flag"], clips[i]["active_probs"],
+                                  clips[i]["rms"], sr, hop_length, confidence_threshold, say, analyses[i], kwargs) for i in live}
+    lists = {i: staged[i][0] for i in live}
+    if use_financial:
+        need = [i for i in live if len(lists[i]) > 10]
         if need:
             kept = FinancialPitchAnalyzer(sr=sr, hop_length=hop_length).filter_ghost_notes_rsi_batch([lists[i] for i in need])
             for i, ev in zip(need, kept):
                 lists[i] = ev
-    return [_harmonic_stage(ev, thr, sr, hop_length, say, kwargs) if ev else [] for ev, (_, thr, _) in zip(lists, staged)]
+    out = [errors[i] if i in errors else (_harmonic_stage(lists[i], staged[i][1], sr, hop_length, say, kwargs) if lists[i] else [])
+           for i in range(len(clips))]
+    if errors and not return_exceptions:
+        first = errors[min(errors)]
+        first.results = out
+        raise first
+    return out

@@ -52,3 +52,24 @@ def test_two_rank_shard_and_gather():
         assert len(ev) == int(durations[ci])
         assert [e["start"] for e in ev] == [10 * k for k in range(len(ev))]
         assert ev[0]["technique"] is None and (len(ev) < 2 or ev[1]["technique"] == "vibrato")
+
+
+def test_eight_ranks_with_empty_ranks_and_eventless_ranks():
+    """world_size 8 (the node the driver's scaling run uses): five clips over eight ranks leave three ranks without a clip,
+    and one rank's only clip has no events -- the padded all_gather must carry zero-row contributions, and the LPT
+    shards must be disjoint, complete and longest-first."""
+    durations = [5.0, 0.0, 3.0, 8.0, 2.0]
+    shards = dist.shard_clips(durations, 8)
+    assert sorted(i for s in shards for i in s) == list(range(5)) and sum(1 for s in shards if not s) == 3
+    assert shards[0] == [3] and shards[1] == [0]
+    with mp.Manager() as m:
+        ret = m.dict()
+        mp.spawn(_worker, args=(8, _free_port(), durations, ret), nprocs=8, join=True)
+        rows = ret["rows"]
+    per_clip = dist.unpack_events(rows)
+    assert sorted(per_clip) == [0, 2, 3, 4] and rows.shape == (18, 10)
+    for ci, ev in per_clip.items():
+        assert len(ev) == int(durations[ci]) and [e["velocity"] for e in ev] == [64 + k for k in range(len(ev))]
+    big = dist.shard_clips(list(np.random.default_rng(0).uniform(30, 330, 512)), 8)
+    loads = [sum(np.random.default_rng(0).uniform(30, 330, 512)[i] for i in s) for s in big]
+    assert max(loads) - min(loads) < 330.0 and all(len(s) >= 60 for s in big)

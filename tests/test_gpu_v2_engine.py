@@ -93,3 +93,23 @@ def test_batched_v2_engine_equals_clip_by_clip():
         np.testing.assert_array_equal(bufs["sdb_col_means"][a:b], np.mean(S, axis=0))
         np.testing.assert_array_equal(bufs["sdb_col_means"][F + a:F + b], np.mean(S[:64], axis=0))
         np.testing.assert_array_equal(bufs["sdb_col_means"][2 * F + a:2 * F + b], np.mean(S[64:], axis=0))
+
+
+def test_batched_v2_engine_with_clips_too_short_for_the_trend_filters():
+    """A clip of fewer than 10 frames makes analyze_array raise IndexError, as the reference does (Bollinger window,
+    financial_analysis.py:113-146); in a folder batch it must not take the other clips' results with it."""
+    import pytest
+    good = [signals.guitar_clip(8.0, sr=22050, seed=21), signals.c_major_scale(22050)]
+    tiny, empty = good[0][:2000].copy(), np.zeros(0, np.float32)
+    eng = AegisFinancialEngine()
+    with pytest.raises(IndexError):
+        eng.analyze_array(tiny)
+    out = eng.analyze_arrays([good[0], tiny, good[1], empty], return_exceptions=True)
+    assert isinstance(out[1], IndexError) and isinstance(out[3], IndexError)
+    for got, y in zip((out[0], out[2]), good):
+        one = eng.analyze_array(y)
+        assert [(e["note"], e["start"], e["end"]) for e in got] == [(e["note"], e["start"], e["end"]) for e in one] and len(one) > 0
+    with pytest.raises(IndexError) as ei:
+        eng.analyze_arrays([good[0], tiny, good[1]])
+    assert len(ei.value.results) == 3 and len(ei.value.results[2]) == len(out[2])
+    assert eng.analyze_arrays([tiny], use_financial=False) == [eng.analyze_array(tiny, use_financial=False)]

@@ -1,10 +1,10 @@
 // Time of the frame kernel's running-energy walk (np.cumsum of squares, float32, one frame per lane, 16 lanes) on an
-// otherwise idle CU: the product's energy_walk against variants of its loop structure.
+// otherwise idle CU: the product's energy_walk against the bare dependent chain (the retired 8-sample-block walk it
+// replaced is recorded in profiles/r2_ubench_walk.txt: 23.7 cycles per add).
 //   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I spectrogram-midi_amd/csrc tools/ubench_walk.hip -o tools/_build/ubench_walk
 #include "../spectrogram-midi_amd/csrc/kernels.hip"
 #include <cstdio>
 namespace aegis {
-#include "walk_old.inc"
 // no LDS in the loop at all: the chain alone (values from registers)
 __device__ __forceinline__ float chain_only(float e, float x, int n) {
     for (int i = 0; i < n; i += 8) {
@@ -33,7 +33,6 @@ __global__ __launch_bounds__(256) void walk_bench(long long *out, float *sink, i
             b = *reinterpret_cast<const float4 *>(q + 4);
         };
         if (V == 0) energy_walk<true>(fetch, row, mp);
-        if (V == 1) energy_walk_old<true>(fetch, row, mp);
         if (V == 2) acc = chain_only(0.f, stage[lane], 1568);
     }
     __builtin_amdgcn_s_waitcnt(0);
@@ -52,13 +51,11 @@ int main() {
     const size_t lds = 10240 * 4 + 16 * stride * 4;
     for (int r = 0; r < 2; ++r) {
         hipLaunchKernelGGL(aegis::walk_bench<0>, dim3(1), dim3(256), lds, 0, d, sink, mp, stride);
-        hipLaunchKernelGGL(aegis::walk_bench<1>, dim3(1), dim3(256), lds, 0, d, sink, mp, stride);
         hipLaunchKernelGGL(aegis::walk_bench<2>, dim3(1), dim3(256), lds, 0, d, sink, mp, stride);
     }
     hipDeviceSynchronize();
     hipMemcpy(h, d, 32, hipMemcpyDeviceToHost);
     printf("energy_walk (product)   %8lld ticks = %.1f per add\n", h[0], h[0] / 1568.0);
-    printf("energy_walk (round-2a)  %8lld ticks = %.1f per add\n", h[1], h[1] / 1568.0);
     printf("chain only (registers)  %8lld ticks = %.1f per add\n", h[2], h[2] / 1568.0);
     return 0;
 }
