@@ -142,6 +142,15 @@ int aegis_cqt_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_
                      int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *d_mag_out,
                      void *stream, int32_t sync);
 
+/* librosa.feature.chroma_cqt(y, sr) as the auto-matcher calls it (aegis_engine_core/auto_matcher.py:68-69) behind the
+ * magnitudes of aegis_cqt: the folding matrix filters.cq_to_chroma -- every CQT bin feeds exactly one chroma class,
+ * bin_class[n_bins] with entries in [0, n_chroma) -- and util.normalize(norm=inf) per frame, both on the device, so only
+ * n_chroma x F floats per clip come back instead of n_bins x F.  Host PCM in; chroma_out: per clip [n_chroma, F_clip]
+ * C-order, clip after clip.  `fmin` is the bank's (tuning-shifted) lowest frequency.  n_chroma <= 24.  Blocking. */
+int aegis_chroma_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
+                     int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, int32_t n_chroma,
+                     const int32_t *bin_class, float *chroma_out);
+
 /* --- incremental analysis of one clip (BASELINE.json configs[4]; the reference has no streaming path:
  * financial_app_realtime.py analyses whole files).  Samples are pushed in any chunk sizes; every frame whose
  * centred 2048-sample window is complete is analysed at once (mel, YIN, observation) and the Viterbi advances

@@ -1,7 +1,10 @@
 """ctypes binding of libaegis_hip.so (include/aegis_hip.h).  Fails loudly when the
 extension has not been built: `python -c "import __graft_entry__ as g; g.build()"`."""
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 
 import numpy as np
 
@@ -42,7 +45,7 @@ class Outputs(C.Structure):
 EXPORTS = ("aegis_abi_version", "aegis_create", "aegis_destroy", "aegis_last_error", "aegis_frames_for",
            "aegis_analyze_batch", "aegis_analyze_batch_device", "aegis_get_table", "aegis_get_param",
            "aegis_debug_fetch", "aegis_set_profiling", "aegis_last_kernel_ms", "aegis_rake_patterns", "aegis_set_table", "aegis_last_kernel_launches", "aegis_trend", "aegis_ghost_rsi",
-           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt", "aegis_cqt_device",
+           "aegis_stream_open", "aegis_stream_push", "aegis_stream_close", "aegis_stream_free", "aegis_cqt", "aegis_cqt_device", "aegis_chroma_cqt",
            "aegis_extract_events", "aegis_render_smf", "aegis_events_last_error")
 
 _lib = None
@@ -101,6 +104,9 @@ def load():
     lib.aegis_cqt_device.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32, C.c_double,
                                      C.c_double, C.c_void_p, C.c_void_p, C.c_int32]
     lib.aegis_cqt_device.restype = C.c_int
+    lib.aegis_chroma_cqt.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64), C.c_int32, C.c_int32, C.c_int32,
+                                     C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.aegis_chroma_cqt.restype = C.c_int
     lib.aegis_set_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
     lib.aegis_set_table.restype = C.c_int
     lib.aegis_get_table.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
@@ -123,6 +129,21 @@ _TABLE_DTYPES = {"mel_dense": np.float32}
 _DEBUG_DTYPES = {"persistent_fallbacks": np.int64, "obs_cycles": np.int64, "cqt_cycles": np.int64, "viterbi_cycles": np.int64, "viterbi_spans": np.int64, "frame_cycles": np.int64, "states": np.int32, "melpow": np.float32}
 
 
+_live_handles = weakref.WeakSet()
+
+
+@atexit.register
+def _close_live_handles():
+    """Handles still alive at interpreter exit (a module global, a handle held by the traceback of the exception that is
+    ending the process) are closed here, while the interpreter and the HIP runtime are both fully alive: atexit callbacks
+    run before module teardown.  `Handle.__del__` does nothing once finalisation has begun."""
+    for h in list(_live_handles):
+        try:
+            h.close()
+        except Exception:       # noqa: BLE001 -- exit must go on
+            pass
+
+
 class Handle:
     """One analyze context (tables + workspace + stream) on one GPU.  device=-1 builds the
     host tables only (no GPU touched).  pyin_init: "unvoiced" (default; librosa core/pitch.py::pyin: p_init zero on
@@ -140,6 +161,7 @@ class Handle:
         if rc != OK:
             raise AegisError(rc, self.lib.aegis_last_error(None).decode())
         self._h = h
+        _live_handles.add(self)
         self.sr, self.hop, self.n_fft, self.n_mels, self.device = sample_rate, hop_length, n_fft, n_mels, device
         if scipy_tables:
             self._load_scipy_tables()
@@ -167,10 +189,14 @@ class Handle:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.lib.aegis_destroy(self._h)
-            self._h = None
+            h, self._h = self._h, None
+            self.lib.aegis_destroy(h)
 
-    __del__ = close
+    def __del__(self):
+        # from the garbage collector: never during interpreter finalisation (the atexit hook above has closed every live
+        # handle by then; a handle created later than that is left to the process exit)
+        if not sys.is_finalizing():
+            self.close()
 
     def _check(self, rc):
         if rc != OK:
@@ -344,6 +370,28 @@ class Handle:
             o += Fc * n_bins
         return res
 
+    def chroma_cqt(self, clips, bin_class, n_chroma=12, n_bins=252, bins_per_octave=36, fmin=32.70319566257483, filter_scale=1.0):
+        """aegis_chroma_cqt: |CQT| folded into chroma classes (bin_class[n_bins] -> 0..n_chroma-1) and divided by the frame
+        maximum, all on the device: float32 [n_chroma, 1 + len//hop] per clip."""
+        clips = [np.ascontiguousarray(c, dtype=np.float32) for c in clips]
+        n = len(clips)
+        if n == 0:
+            return []
+        ptrs = (C.c_void_p * n)(*[c.ctypes.data for c in clips])
+        lens = (C.c_int64 * n)(*[len(c) for c in clips])
+        frames = [self.frames_for(len(c)) for c in clips]
+        cls = np.ascontiguousarray(bin_class, dtype=np.int32)
+        if len(cls) != n_bins:
+            raise ValueError("bin_class needs one entry per CQT bin")
+        out = np.empty(sum(frames) * n_chroma, np.float32)
+        self._check(self.lib.aegis_chroma_cqt(self._h, ptrs, lens, n, n_bins, bins_per_octave, float(fmin), float(filter_scale),
+                                              n_chroma, cls.ctypes.data, out.ctypes.data))
+        res, o = [], 0
+        for Fc in frames:
+            res.append(out[o:o + Fc * n_chroma].reshape(n_chroma, Fc).copy())
+            o += Fc * n_chroma
+        return res
+
     def cqt_device(self, d_pcm_ptr, sample_offsets, d_out_ptr, n_bins=84, bins_per_octave=12, fmin=32.70319566257483,
                    filter_scale=1.0, stream=None, sync=True):
         """aegis_cqt_device: PCM and |CQT| resident in device memory (raw pointers as ints)."""
@@ -422,4 +470,6 @@ class Stream:
             self.lib.aegis_stream_free(self._s)
             self._s = None
 
-    __del__ = free
+    def __del__(self):
+        if not sys.is_finalizing():
+            self.free()

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -17,6 +18,7 @@
 #include <numeric>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/aegis_hip.h"
@@ -49,6 +51,7 @@ struct aegis_handle {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;            // Viterbi stream of the time-chunked pipeline
+    bool troughs_off = false;                 // AEGIS_TROUGHS_IN_FRAME=0 at create
     bool cmnd_off = false;                    // AEGIS_CMND_IN_FRAME=0 at create: pyin_obs_kernel walks the CMND cumsum (tests compare the two paths)
     bool debug_stages = false;                // AEGIS_DEBUG_STAGES=1 at create: pyin_obs also writes the CMND rows ("yin") for the stage tests
     int64_t chunk_start = 512;                // first time chunk (AEGIS_CHUNK_START), later ones grow by chunk_growth_pct up to time_chunk
@@ -88,7 +91,7 @@ struct aegis_handle {
     bool persist_pending = false;             // a persistent launch ran since the abort flag was last read
     bool persistent = true;                   // one Viterbi launch per balanced pass (AEGIS_VITERBI_PERSISTENT=0: one per chunk)
     CqtBank cqt_bank;
-    DevBuf q_pcm, q_soff, q_foff, q_toff, q_out;
+    DevBuf q_pcm, q_soff, q_foff, q_toff, q_out, q_chroma, q_cls;
     DevBuf t_x, t_off, t_a, t_b, t_c, t_d, t_e, t_i8, t_i64a, t_i64b;   // trend-filter staging
     DevBuf t_pa;                              // scratch of the fused pitch analysis: 12 rows of doubles + 1 of bytes
     DevBuf io_pcm, io_f0, io_voiced, io_vprob, io_rms, io_rake, io_sdb, io_bin, io_colmean;
@@ -188,6 +191,9 @@ PassParams base_params(const Tables &t) {
 int cmnd_in_frame(const aegis_handle *h) {
     return (!h->cmnd_off && !h->debug_stages && frame_cmnd_supported(h->tab.max_period)) ? 1 : 0;
 }
+// ... and finds the CMND's troughs there as well (AEGIS_TROUGHS_IN_FRAME=0 at create: pyin_obs_kernel loads the CMND row and
+// finds them, the round-3 path; tests compare the two)
+int troughs_in_frame(const aegis_handle *h) { return (cmnd_in_frame(h) && !h->troughs_off) ? 1 : 0; }
 
 void free_buf(DevBuf &b) {
     if (b.p) (void)hipFree(b.p);
@@ -271,6 +277,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     h->max_frames_per_pass = c.max_frames_per_pass;
 
     h->lag_stride = (h->tab.max_period + 1 + 7) & ~7;
+    // a dfn row also holds the frame's trough list when the frame kernel finds the troughs (PassParams::troughs)
+    h->lag_stride = std::max<int32_t>(h->lag_stride, (trough_row_doubles_host(h->tab.n_lags) + 7) & ~7);
     h->yin_stride = (h->tab.n_lags + 7) & ~7;
     h->obs_stride = (h->tab.n_bins + 7) & ~7;
     if (c.device == -1) { *out = h; return AEGIS_OK; }   // host tables only
@@ -296,6 +304,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     }
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
     if (const char *e = std::getenv("AEGIS_CMND_IN_FRAME")) h->cmnd_off = (e[0] == '0');
+    if (const char *e = std::getenv("AEGIS_TROUGHS_IN_FRAME")) h->troughs_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
@@ -381,19 +390,39 @@ static void destroy_now(aegis_handle *h) noexcept {
     auto T = [&](const char *what) { if (trace) { std::fprintf(stderr, "[aegis destroy] %s\n", what); std::fflush(stderr); } };
     T("hipSetDevice");
     (void)hipSetDevice(h->device);
-    const char *exp_ = std::getenv("AEGIS_DESTROY_EXPERIMENT");       // temporary: which teardown order does not hang
-    const int ex = exp_ ? std::atoi(exp_) : 0;
-    if (ex == 1) { T("device sync"); (void)hipDeviceSynchronize(); }
-    if (ex == 3) {      // plain streams first
-        T("plain streams first");
-        for (hipStream_t *q : {&h->stream, &h->stream2, &h->stream3, &h->stream4}) if (*q) { (void)hipStreamSynchronize(*q); (void)hipStreamDestroy(*q); *q = nullptr; }
+    // Bounded wait first: the handle's streams normally are idle here (every blocking entry synchronises before it returns).
+    // If something is still running after ten seconds -- a caller that enqueued with sync = 0 and never waited, a wedged
+    // device -- the GPU objects are leaked rather than waited for: a teardown (Handle.__del__ runs it from the garbage
+    // collector, possibly while an exception unwinds) must never be the call that hangs a process.
+    {
+        std::vector<hipStream_t> all{h->stream, h->stream2, h->stream3, h->stream4};
+        for (auto &ss : h->split) for (hipStream_t q : {ss.frame_a, ss.frame_b, ss.viterbi}) all.push_back(q);
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            bool busy = false;
+            for (hipStream_t q : all) if (q && hipStreamQuery(q) == hipErrorNotReady) busy = true;
+            if (!busy) break;
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(10)) {
+                std::fprintf(stderr, "libaegis_hip: aegis_destroy: work still running on the handle's streams after 10 s; its device memory and streams are leaked\n");
+                (void)hipGetLastError();
+                delete h;
+                return;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(1));
+        }
+        (void)hipGetLastError();
     }
-    if (ex == 4 && h->copy_event) { T("copy event first"); (void)hipEventDestroy(h->copy_event); h->copy_event = nullptr;
-        for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
-        h->sync_events.clear(); }
+    // The CU-masked streams own their hardware queues (plain streams draw from the runtime's pool), so destroying one really
+    // tears a queue down -- and hipStreamDestroy sat in that for ever (gpurun_out/call53.log) after
+    // a pass whose streams had waited on each other's events with timing events recorded between them (profiling on, the
+    // host-buffer entry's schedule), although every stream of the handle had been synchronised one by one.  A device-wide
+    // synchronisation first makes the runtime retire what it still tracks across streams; with it the same teardown
+    // returns (tools/exit_hang_probe.py, matrix in profiles/r4_exit_hang_probe.txt).
+    T("device sync");
+    (void)hipDeviceSynchronize();
     for (auto &ss : h->split)
         for (hipStream_t q : {ss.frame_a, ss.frame_b, ss.viterbi})
-            if (q) { T("sync masked stream"); (void)hipStreamSynchronize(q); if (ex == 2) continue; T("destroy masked stream"); (void)hipStreamDestroy(q); }
+            if (q) { T("destroy masked stream"); (void)hipStreamDestroy(q); }
     T("sync stream"); if (h->stream) (void)hipStreamSynchronize(h->stream);
     T("sync stream2"); if (h->stream2) (void)hipStreamSynchronize(h->stream2);
     T("sync stream3"); if (h->stream3) (void)hipStreamSynchronize(h->stream3);
@@ -413,7 +442,7 @@ static void destroy_now(aegis_handle *h) noexcept {
             free_buf(*b);
     T("free staging");
     for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->finite_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
-                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->t_pa, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
+                      &h->t_i8, &h->t_i64a, &h->t_i64b, &h->t_pa, &h->q_pcm, &h->q_soff, &h->q_foff, &h->q_toff, &h->q_out, &h->q_chroma, &h->q_cls, &h->io_pcm, &h->io_f0, &h->io_voiced, &h->io_vprob, &h->io_rms, &h->io_rake,
                       &h->io_sdb, &h->io_bin, &h->io_colmean})
         free_buf(*b);
     T("destroy streams");
@@ -835,7 +864,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.n_clips = nc; p.n_frames = fp;
         p.dfn = static_cast<double *>(w.dfn.p); p.lag_stride = h->lag_stride;
         p.yin = (py && h->debug_stages) ? static_cast<double *>(w.yin.p) : nullptr; p.yin_stride = h->yin_stride;
-        p.cmnd_in_frame = cmnd_in_frame(h);
+        p.cmnd_in_frame = cmnd_in_frame(h); p.troughs = troughs_in_frame(h);
         p.logobs = static_cast<double *>(w.logobs.p); p.obs_stride = h->obs_stride;
         p.logunv = static_cast<double *>(w.logunv.p);
         p.obs_seg = static_cast<int32_t *>(w.obs_seg.p);
@@ -1148,6 +1177,51 @@ int aegis_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples
     } catch (...) { return abi_fail(h); }
 }
 
+int aegis_chroma_cqt(aegis_handle *h, const float *const *pcm, const int64_t *n_samples, int32_t n_clips,
+                     int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, int32_t n_chroma,
+                     const int32_t *bin_class, float *chroma_out) {
+    try {
+    if (!h) return AEGIS_ERR_INVALID;
+    if (n_clips < 0 || (n_clips > 0 && (!pcm || !n_samples || !chroma_out)) || !bin_class) { h->err = "null argument"; return AEGIS_ERR_INVALID; }
+    if (n_clips == 0) return AEGIS_OK;
+    if (n_chroma < 1 || n_chroma > 24) { h->err = "n_chroma must be 1..24"; return AEGIS_ERR_INVALID; }
+    if (h->device < 0) { h->err = "handle was created with device=-1 (host tables only)"; return AEGIS_ERR_DEVICE; }
+    std::lock_guard<std::mutex> lock(h->mu);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    int rc;
+    if ((rc = cqt_bank_locked(h, n_bins, bins_per_octave, fmin, filter_scale, s)) != AEGIS_OK) return rc;
+    for (int b = 0; b < n_bins; ++b)
+        if (bin_class[b] < 0 || bin_class[b] >= n_chroma) { h->err = "bin_class entries must lie in [0, n_chroma)"; return AEGIS_ERR_INVALID; }
+    std::vector<int64_t> soff(n_clips + 1, 0);
+    int64_t F = 0;
+    for (int i = 0; i < n_clips; ++i) {
+        if (n_samples[i] < 0 || (n_samples[i] > 0 && !pcm[i])) { h->err = "bad clip " + std::to_string(i); return AEGIS_ERR_INVALID; }
+        soff[i + 1] = soff[i] + n_samples[i];
+        F += 1 + n_samples[i] / h->tab.hop;
+    }
+    if ((rc = ensure(h, h->q_pcm, (size_t)std::max<int64_t>(soff[n_clips], 1) * 4)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_out, (size_t)F * n_bins * 4)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_chroma, (size_t)F * n_chroma * 4)) != AEGIS_OK) return rc;
+    if ((rc = ensure(h, h->q_cls, (size_t)n_bins * 4)) != AEGIS_OK) return rc;
+    HIPCHK(h, hipMemcpyAsync(h->q_cls.p, bin_class, (size_t)n_bins * 4, hipMemcpyHostToDevice, s));
+    for (int i = 0; i < n_clips; ++i)
+        if (n_samples[i] > 0)
+            HIPCHK(h, hipMemcpyAsync(static_cast<float *>(h->q_pcm.p) + soff[i], pcm[i], n_samples[i] * 4, hipMemcpyHostToDevice, s));
+    int64_t Fd = 0;
+    if ((rc = cqt_launch_locked(h, static_cast<const float *>(h->q_pcm.p), soff.data(), n_clips, static_cast<float *>(h->q_out.p), s, &Fd)) != AEGIS_OK) return rc;
+    begin_event(h, "chroma", s);
+    launch_chroma_fold(static_cast<const float *>(h->q_out.p), static_cast<const int64_t *>(h->q_foff.p), n_clips, F, n_bins, n_chroma,
+                       static_cast<const int32_t *>(h->q_cls.p), static_cast<float *>(h->q_chroma.p), s);
+    end_event(h, s);
+    HIPCHK(h, hipGetLastError());
+    HIPCHK(h, hipMemcpyAsync(chroma_out, h->q_chroma.p, (size_t)F * n_chroma * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (h->profiling) collect_events(h);
+    return AEGIS_OK;
+    } catch (...) { return abi_fail(h); }
+}
+
 int aegis_cqt_device(aegis_handle *h, const float *d_pcm, const int64_t *sample_offsets, int32_t n_clips,
                      int32_t n_bins, int32_t bins_per_octave, double fmin, double filter_scale, float *d_mag_out,
                      void *stream, int32_t sync) {
@@ -1185,7 +1259,7 @@ static PassParams stream_params(aegis_stream *st, const int64_t *dm) {
     p.n_clips = 1;
     p.dfn = static_cast<double *>(st->dfn.p); p.lag_stride = h->lag_stride;
     p.yin = nullptr; p.yin_stride = h->yin_stride;
-    p.cmnd_in_frame = cmnd_in_frame(h);
+    p.cmnd_in_frame = cmnd_in_frame(h); p.troughs = troughs_in_frame(h);
     p.logobs = static_cast<double *>(st->logobs.p); p.obs_stride = h->obs_stride;
     p.logunv = static_cast<double *>(st->logunv.p);
     p.obs_seg = static_cast<int32_t *>(st->obs_seg.p);

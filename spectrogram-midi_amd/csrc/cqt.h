@@ -39,6 +39,9 @@ struct CqtArgs {
 // tile_off: device [n_clips+1] prefix of ceil(F_clip / kCqtSlideFrames) (sliding-window kernel), or nullptr
 constexpr int kCqtSlideFrames = 48;
 void launch_cqt(const CqtArgs &a, const CqtBank &b, const int64_t *tile_off, int64_t n_slide_tiles, hipStream_t s);
+// chroma folding + per-frame max normalisation of per-clip [n_bins, F] magnitudes -> per-clip [n_chroma, F]; n_bins <= 256, n_chroma <= 24
+void launch_chroma_fold(const float *mag, const int64_t *frame_off, int n_clips, int64_t n_frames, int n_bins, int n_chroma,
+                        const int32_t *bin_class, float *out, hipStream_t s);
 hipError_t cqt_configure();
 hipError_t cqt_debug_fetch(long long *dst);   // cycle counters of one workgroup (zeros unless built with CQT_ABLATE&8)
 

@@ -259,7 +259,23 @@ __device__ __forceinline__ int ring_idx(int u) {
 // Groups (of 4 k-steps) that tile T's A fragments are fetched ahead of their MFMAs.  Tile T is only ever active
 // together with tiles 0..T-1, so a group lasts >= (T+1) x 12 MFMAs = (T+1) x 384 cycles: the longest filters run
 // alone in the outer passes and need the deepest queue.  Must divide the 4 groups of a pass.
-__host__ __device__ constexpr int slide_lookahead(int T) { return T == 0 ? 4 : T <= 3 ? 2 : 1; }
+// Round 4: queues of 8 / 8 / 4 groups (tile 0, tiles 1..3, the others) instead of 4 / 2 / 1: 4.27 -> 4.10 ms for 64 x 30 s.
+// Depth is not what bounds the outer passes, though: the compiler places the waits for these loads, vector loads return
+// in order, and the number of refills issued between a request and its use is a run-time figure (the tile chain
+// branches), so every group opens with s_waitcnt vmcnt(<= 3) and, from the fourth group of a pair on, vmcnt(0) -- whatever
+// the depth, a group never has more than a handful of fragments in flight behind it.
+#ifndef CQT_LA0
+#define CQT_LA0 8
+#endif
+#ifndef CQT_LA1
+#define CQT_LA1 8
+#endif
+#ifndef CQT_LA2
+#define CQT_LA2 4
+#endif
+__host__ __device__ constexpr int slide_lookahead(int T) { return T == 0 ? CQT_LA0 : T <= 3 ? CQT_LA1 : CQT_LA2; }
+constexpr int kSlotDepth = 8;           // groups of a pair of passes: the deepest queue (slot indices stay compile-time constants)
+static_assert(kSlotDepth % CQT_LA0 == 0 && kSlotDepth % CQT_LA1 == 0 && kSlotDepth % CQT_LA2 == 0, "queue depths must divide 8");
 
 #if CQT_ABLATE & 8
 __device__ long long g_cqt_dbg[16];
@@ -342,7 +358,7 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
         return *reinterpret_cast<const f32x4 *>(bank_b + off);
 #endif
     };
-    f32x4 slot[NT][kGroups];                             // tile T uses the first slide_lookahead(T) entries
+    f32x4 slot[NT][kSlotDepth];                          // tile T uses the first slide_lookahead(T) entries
     int na_next = active_tiles(0);
     {                                                    // queues of the tiles active in pass 0
         auto fill0 = [&](auto self, auto tc) -> void {
@@ -431,12 +447,15 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
                     if constexpr (T < NT) {
                         if (T < na) {
                             constexpr int LA = slide_lookahead(T);
+                            const int si = (hp * kGroups + g) % LA;      // compile-time: hp and g are unrolled, q2 is even
 #pragma unroll
                             for (int e = 0; e < 4; ++e)
 #pragma unroll
                                 for (int ct = 0; ct < 3; ++ct)
-                                    acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[T][g % LA][e], b[ct][e], acc[T][ct], 0, 0, 0);
-                            if (g + LA < kGroups || hp == 0 || T < ncont) slot[T][g % LA] = frag(T, q * kGroups + g + LA);
+                                    acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[T][si][e], b[ct][e], acc[T][ct], 0, 0, 0);
+                            // the slot just consumed takes the group LA further down the stream: inside this pair of passes, or in
+                            // the next pair if the tile is still active there
+                            if (hp * kGroups + g + LA < 2 * kGroups || T < ncont) slot[T][si] = frag(T, q * kGroups + g + LA);
                             self(self, std::integral_constant<int, T + 1>{});
                         }
                     }
@@ -503,6 +522,50 @@ hipError_t cqt_debug_fetch(long long *dst) { return hipMemcpyFromSymbol(dst, HIP
 #else
 hipError_t cqt_debug_fetch(long long *dst) { for (int i = 0; i < 16; ++i) dst[i] = 0; return hipSuccess; }
 #endif
+
+// ------------------------------------------------------------------------------------------
+// chroma_cqt's two steps behind the magnitudes (librosa.feature.chroma_cqt, auto_matcher.py:68-69): the 0/1 folding
+// matrix filters.cq_to_chroma (every CQT bin belongs to exactly one chroma class: bin_class) and util.normalize(norm=inf)
+// per frame (a frame whose maximum is below float tiny is left as it is).  One thread per frame: the magnitude rows are
+// read with consecutive threads on consecutive frames, the n_chroma sums stay in registers (bins added in ascending
+// order, float32 -- a BLAS product's order is unspecified and differs from it in the last bit at most).
+// ------------------------------------------------------------------------------------------
+constexpr int kMaxChroma = 24;
+__global__ __launch_bounds__(256) void chroma_fold_kernel(const float *__restrict__ mag, const int64_t *__restrict__ frame_off, int n_clips,
+                                                          int64_t n_frames, int n_bins, int n_chroma, const int32_t *__restrict__ bin_class,
+                                                          float *__restrict__ out) {
+    __shared__ int cls[256];
+    for (int i = threadIdx.x; i < n_bins; i += blockDim.x) cls[i] = bin_class[i];
+    __syncthreads();
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f >= n_frames) return;
+    const int c = clip_of(frame_off, n_clips, f);
+    const int64_t F = frame_off[c + 1] - frame_off[c], t = f - frame_off[c];
+    const float *__restrict__ m = mag + (int64_t)n_bins * frame_off[c] + t;
+    float acc[kMaxChroma];
+#pragma unroll
+    for (int k = 0; k < kMaxChroma; ++k) acc[k] = 0.0f;
+    for (int b = 0; b < n_bins; ++b) {
+        const float v = m[(int64_t)b * F];
+        const int k = cls[b];
+#pragma unroll
+        for (int q = 0; q < kMaxChroma; ++q) if (q == k) acc[q] = acc[q] + v;       // registers stay registers
+    }
+    float mx = 0.0f;
+#pragma unroll
+    for (int k = 0; k < kMaxChroma; ++k) if (k < n_chroma) mx = fmaxf(mx, fabsf(acc[k]));
+    const float div = mx < 1.17549435e-38f ? 1.0f : mx;
+    float *__restrict__ o = out + (int64_t)n_chroma * frame_off[c] + t;
+#pragma unroll
+    for (int k = 0; k < kMaxChroma; ++k) if (k < n_chroma) o[(int64_t)k * F] = acc[k] / div;
+}
+
+void launch_chroma_fold(const float *mag, const int64_t *frame_off, int n_clips, int64_t n_frames, int n_bins, int n_chroma,
+                        const int32_t *bin_class, float *out, hipStream_t s) {
+    if (n_frames == 0) return;
+    hipLaunchKernelGGL(chroma_fold_kernel, dim3((unsigned)((n_frames + 255) / 256)), dim3(256), 0, s, mag, frame_off, n_clips, n_frames,
+                       n_bins, n_chroma, bin_class, out);
+}
 
 hipError_t cqt_configure() {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cqt_kernel<kCqtRowTiles>),

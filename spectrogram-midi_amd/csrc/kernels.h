@@ -91,6 +91,9 @@ struct PassParams {
                                          //                   cmnd_in_frame the entries tau >= min_period hold the CMND instead
     int32_t cmnd_in_frame;               // the frame kernel's epilogue forms the CMND (cumsum walk of all its frames at once);
                                          // 0: pyin_obs_kernel walks it frame by frame (stage tests, lag ranges the epilogue cannot hold)
+    int32_t troughs;                     // with cmnd_in_frame: the frame kernel also finds the CMND's troughs and leaves each frame's
+                                         // trough list (count, values, parabolic shifts, lags: kernels.hip trough_row_doubles) in its dfn row
+                                         // instead of the CMND; pyin_obs_kernel starts at the threshold prior
     double *yin;   int32_t yin_stride;   // optional [F][yin_stride]: CMND for lags min..max, written only for the stage tests
     double *logobs; int32_t obs_stride;  // [F][obs_stride]   log(obs+tiny), voiced bins
     double *logunv;                      // [F]               log(unvoiced obs+tiny)
@@ -118,7 +121,8 @@ struct PassParams {
 constexpr int kViterbiChunk = 16;   // steps per composed back-pointer map
 
 void launch_frame(const PassParams &p, const DevTables &t, hipStream_t s);
-bool frame_cmnd_supported(int max_period);   // the frame kernel's LDS holds the CMND rows of a workgroup's frames (PassParams::cmnd_in_frame)
+bool frame_cmnd_supported(int max_period);
+int trough_row_doubles_host(int n_lags);    // doubles of a dfn row that holds a frame's trough list (PassParams::troughs)   // the frame kernel's LDS holds the CMND rows of a workgroup's frames (PassParams::cmnd_in_frame)
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
 bool viterbi_band_applies(const PassParams &p, const DevTables &t);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry

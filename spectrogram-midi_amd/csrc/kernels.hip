@@ -220,6 +220,21 @@ __device__ __forceinline__ void cmnd_walk(double *__restrict__ r, int mp) {
     if (tau + GL - 1 <= mp) { group(ra, rb, tau); tau += GL; }
     for (; tau <= mp; ++tau) { cs = cs + r[tau]; r[tau] = cs; }
 }
+__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(v, o);
+        if (lane >= o) v += nb;
+    }
+    return v;
+}
+
+// Layout of a frame's trough list in its dfn row (PassParams::troughs): [0] the count K (as an integer bit pattern), then
+// from double 8 on th[KM] (CMND value of each trough, ascending lag), tsh[KM] (its parabolic shift) and ti[KM] (int16 lag
+// index); KM = n_lags / 2 + 2 bounds the number of local minima.
+__host__ __device__ inline int trough_km(int n_lags) { return n_lags / 2 + 2; }
+__host__ __device__ inline int trough_row_doubles(int n_lags) { const int km = trough_km(n_lags); return 8 + 2 * km + (km + 3) / 4; }
+
 constexpr size_t kFrameLdsFixed = (size_t)2048 * 16 + 2048 * 4 + 1040 * 4 + 128 * 4 + 16 * 4 + 256 * 4;
 
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
@@ -671,17 +686,71 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         if (wid == 0) __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         FRM_TICK(8)
+        const bool troughs = p.troughs != 0;
 #pragma unroll
         for (int i = 0; i < kFramesPerWg; ++i) {
             double *__restrict__ drow = p.dfn + (fr[i] < 0 ? 0 : fr[i]) * (int64_t)p.lag_stride;
-            const double *__restrict__ cs = row_of(i);
+            double *__restrict__ cs = row_of(i);
 #pragma unroll
             for (int u = 0; u < 3; ++u) {
                 const int tau = tid + 256 * u;
-                if (fr[i] >= 0 && tau >= minp && tau <= mp) drow[tau] = dv[i][u] / (cs[tau] / (double)tau + DBL_MIN);
+                if (fr[i] >= 0 && tau >= minp && tau <= mp) {
+                    const double yv = dv[i][u] / (cs[tau] / (double)tau + DBL_MIN);
+                    if (troughs) cs[tau] = yv;          // the CMND stays in LDS, over the cumsum entry this thread has just read
+                    else drow[tau] = yv;
+                }
             }
         }
         FRM_TICK(9)
+        // ---- troughs of the CMND, compacted (round 4).  pyin_obs_kernel used to load the 495-lag CMND row of every frame
+        // from memory and spend a sixth of its time finding the local minima; here the row is in LDS anyway, so every wave
+        // takes the frames wid, wid + 4, ... of the workgroup, finds the troughs exactly as pyin_obs_kernel does (util.localmin
+        // plus the special first element, contiguous lag chunk per lane, ballot-free prefix scan) and writes, in ascending lag
+        // order, each trough's CMND value, its parabolic shift (pitch.py::_parabolic_interpolation: a function of the three
+        // CMND values around it) and its lag index: a few hundred bytes per frame instead of the 4 KB row, and the
+        // observation kernel starts at the threshold prior.
+        if (troughs) {
+            __syncthreads();
+            const int nl = p.n_lags, KM = trough_km(nl), CH = (nl + 63) >> 6;
+            for (int i = wid; i < nfr; i += 4) {
+                if (fr[i] < 0) continue;                                  // (uniform)
+                const double *__restrict__ y = row_of(i) + minp;
+                unsigned mask = 0;
+                int cnt = 0;
+                for (int r = 0; r < CH; ++r) {
+                    const int k = lane * CH + r;
+                    if (k < nl) {
+                        const double yi = y[k];
+                        bool tr;
+                        if (k == 0) tr = yi < y[1];
+                        else if (k == nl - 1) tr = yi < y[k - 1];
+                        else tr = (yi < y[k - 1]) && (yi <= y[k + 1]);
+                        if (tr) { mask |= 1u << r; ++cnt; }
+                    }
+                }
+                const int incl = wave_incl_scan(cnt, lane);
+                const int K = __shfl(incl, 63);
+                double *__restrict__ trow = p.dfn + fr[i] * (int64_t)p.lag_stride;
+                int16_t *__restrict__ tiv = reinterpret_cast<int16_t *>(trow + 8 + 2 * KM);
+                if (lane == 0) trow[0] = __longlong_as_double((long long)K);
+                int pos = incl - cnt;
+                for (int r = 0; r < CH; ++r)
+                    if (mask & (1u << r)) {
+                        const int k = lane * CH + r;
+                        double shift = 0.0;
+                        if (k > 0 && k < nl - 1) {
+                            const double ym = y[k - 1], y0 = y[k], yp = y[k + 1];
+                            const double a = yp + ym - 2.0 * y0;
+                            const double b = (yp - ym) / 2.0;
+                            if (fabs(b) < fabs(a)) shift = -b / a;
+                        }
+                        trow[8 + pos] = y[k];
+                        trow[8 + KM + pos] = shift;
+                        tiv[pos] = (int16_t)k;
+                        ++pos;
+                    }
+            }
+        }
     }
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 128)
     if (blockIdx.x == 1000 && (tid == 0 || tid == 64)) { for (int k = 0; k < 10; ++k) g_frm_dbg[(tid ? 12 : 0) + k] = facc[k]; }
@@ -699,15 +768,6 @@ hipError_t frame_debug_fetch(long long *dst) { for (int i = 0; i < 24; ++i) dst[
 // ------------------------------------------------------------------------------------------
 constexpr int kKMax = 512;    // troughs per frame (n_lags <= 1023)
 constexpr int kMaxRounds = 8; // kKMax / 64
-
-__device__ __forceinline__ int wave_incl_scan(int v, int lane) {
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int nb = __shfl_up(v, o);
-        if (lane >= o) v += nb;
-    }
-    return v;
-}
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ int dpp_imin(int v) {
@@ -789,6 +849,21 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
     const int mp = p.max_period, minp = p.min_period;
     const double *__restrict__ dr = p.dfn + f * (int64_t)p.lag_stride;
     wave_sync();                            // the previous frame's output row has been read out of this wave's buffers
+    int K = 0;
+    double *tsh = y;                        // trough shifts (PassParams::troughs) sit where the CMND row would: read before `row` is written
+    if (p.troughs) {
+        // the frame kernel's epilogue has found the troughs already (frame_yin_kernel): count, values, parabolic shifts, lags
+        const int KMt = trough_km(nl);
+        K = __builtin_amdgcn_readfirstlane((int)__double_as_longlong(dr[0]));
+        const int16_t *__restrict__ tiv = reinterpret_cast<const int16_t *>(dr + 8 + 2 * KMt);
+        for (int k = lane; k < K; k += 64) {
+            const double h = dr[8 + k], sh = dr[8 + KMt + k];
+            const int16_t ix = tiv[k];
+            th[k] = h; tsh[k] = sh; ti[k] = ix;
+        }
+        wave_sync();
+        OBS_TICK(0)
+    } else {
     if (p.cmnd_in_frame) {
         // the frame kernel's epilogue has formed the CMND already (dfn[min_period..max_period] holds it): load and go on
         for (int base = lane; base < nl; base += 320) {
@@ -876,13 +951,14 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
         }
     }
     const int incl = wave_incl_scan(cnt, lane);
-    const int K = __shfl(incl, 63);
+    K = __shfl(incl, 63);
     {
         int k = incl - cnt;
         for (int r = 0; r < CH; ++r)
             if (mask & (1u << r)) { const int i = lane * CH + r; th[k] = y[i]; ti[k] = (int16_t)i; ++k; }
     }
     wave_sync();
+    }   // troughs found here
 
     OBS_TICK(3)
     double vp = 0.0;
@@ -994,7 +1070,8 @@ __global__ __launch_bounds__(512, 4) void pyin_obs_kernel(PassParams p, DevTable
                     if (pr != 0.0) {
                         const int i = ti[k];
                         double shift = 0.0;
-                        if (i > 0 && i < nl - 1) {
+                        if (p.troughs) shift = tsh[k];
+                        else if (i > 0 && i < nl - 1) {
                             const double ym = y[i - 1], y0 = y[i], yp = y[i + 1];
                             const double a = yp + ym - 2.0 * y0;
                             const double b = (yp - ym) / 2.0;
@@ -1325,6 +1402,7 @@ static int frame_batch_fpw(int max_period) {
     while (fpw > 2 && kFrameLdsFixed + (size_t)fpw * stride * 4 > 80 * 1024) fpw -= 2;
     return fpw;
 }
+int trough_row_doubles_host(int n_lags) { return trough_row_doubles(n_lags); }
 bool frame_cmnd_supported(int max_period) {
     // the epilogue keeps three lags per thread and frame in registers and one row per frame in the LDS the loop has freed
     if (max_period + 1 > 3 * 256) return false;

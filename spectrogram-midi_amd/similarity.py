@@ -3,8 +3,8 @@
 Mirror of `_calculate_similarity` (reference aegis_engine_core/auto_matcher.py:13-89): 0.4 x cosine of the two
 128-band mel power spectrograms + 0.6 x cosine of the two `chroma_cqt` matrices, clipped to [0, 1]; inputs shorter
 than 0.5 s score 0.  The mel spectrograms come from the analyze path (stage MEL) and the 252-bin constant-Q
-magnitudes from `aegis_cqt` (7 octaves x 36 bins from C1 on the MFMA units); only the 12 x 252 chroma folding and
-the two dot products run on the host.
+magnitudes from `aegis_chroma_cqt` (7 octaves x 36 bins from C1 on the MFMA units, folded into the 12 chroma classes
+and normalised per frame on the device); only the two dot products run on the host.
 
 `chroma_cqt` leaves `tuning=None`, so librosa first estimates each signal's tuning (a `piptrack` histogram over the
 36-bins-per-octave grid) and shifts the filter bank by it; `estimate_tuning` below does the same on the host (one STFT of
@@ -83,14 +83,31 @@ def chroma_cqt(handle, clips, n_chroma=12, n_octaves=7, bins_per_octave=36, fmin
     `tuning=None` estimates it per clip as librosa does; a number fixes it (0.0 = the nominal grid)."""
     n_bins = n_octaves * bins_per_octave
     tunings = [estimate_tuning(c, handle.sr, bins_per_octave) if tuning is None else float(tuning) for c in clips]
-    mags = [None] * len(clips)
+    fold = cq_to_chroma(n_bins, bins_per_octave, n_chroma, fmin)
+    if n_chroma > 24 or not np.array_equal(fold.sum(axis=0), np.ones(n_bins, np.float32)):
+        return _chroma_cqt_host_fold(handle, clips, tunings, fold, n_bins, bins_per_octave, fmin)
+    # every CQT bin feeds exactly one chroma class: folding and the per-frame max normalisation run on the device behind
+    # the magnitudes (aegis_chroma_cqt), and n_chroma x F floats come back instead of n_bins x F
+    cls = np.argmax(fold, axis=0).astype(np.int32)
+    out = [None] * len(clips)
     for tn in sorted(set(tunings)):                           # one filter bank per distinct tuning
+        sel = [i for i, x in enumerate(tunings) if x == tn]
+        res = handle.chroma_cqt([clips[i] for i in sel], cls, n_chroma=n_chroma, n_bins=n_bins, bins_per_octave=bins_per_octave,
+                                fmin=fmin * 2.0 ** (tn / bins_per_octave))
+        for i, ch in zip(sel, res):
+            out[i] = ch
+    return out
+
+
+def _chroma_cqt_host_fold(handle, clips, tunings, fold, n_bins, bins_per_octave, fmin):
+    """chroma_cqt with the folding matrix applied on the host (a folding matrix that is not 0/1 with one class per bin)."""
+    mags = [None] * len(clips)
+    for tn in sorted(set(tunings)):
         sel = [i for i, x in enumerate(tunings) if x == tn]
         res = handle.cqt([clips[i] for i in sel], n_bins=n_bins, bins_per_octave=bins_per_octave,
                          fmin=fmin * 2.0 ** (tn / bins_per_octave))
         for i, C in zip(sel, res):
             mags[i] = C
-    fold = cq_to_chroma(n_bins, bins_per_octave, n_chroma, fmin)
     out = []
     for C in mags:
         chroma = fold @ C

@@ -172,3 +172,24 @@ def test_device_entry_equals_the_host_entry():
         np.testing.assert_array_equal(got[o:o + Fc * 84].reshape(84, Fc), w)
         o += Fc * 84
     h.close()
+
+
+def test_chroma_folded_on_the_device_equals_the_host_fold():
+    """aegis_chroma_cqt (folding + per-frame max normalisation behind the magnitudes, on the device) against the same two
+    steps done by NumPy on the magnitudes aegis_cqt returns: same bins added, float32, so equal to rounding -- on a ragged
+    batch with an empty clip, a silent one (frames left un-normalised) and one shorter than a hop."""
+    from spectrogram_midi_amd import similarity
+    h = _lib.Handle()
+    clips = [signals.polyphonic_clip(2.0, seed=3), np.zeros(0, np.float32), np.zeros(30000, np.float32),
+             signals.guitar_clip(1.3, seed=4)[:300], signals.guitar_clip(3.1, seed=5)]
+    tunings = [0.0] * len(clips)
+    fold = similarity.cq_to_chroma(252, 36, 12)
+    dev = similarity.chroma_cqt(h, clips, tuning=0.0)
+    host = similarity._chroma_cqt_host_fold(h, clips, tunings, fold, 252, 36, similarity._C1)
+    for a, b, y in zip(dev, host, clips):
+        assert a.shape == b.shape == (12, 1 + len(y) // 512) and a.dtype == np.float32
+        np.testing.assert_allclose(a, b, rtol=0, atol=2e-6)
+    assert not dev[2].any() and dev[0].max() == 1.0
+    with pytest.raises(ValueError):
+        h.chroma_cqt(clips[:1], np.zeros(5, np.int32))
+    h.close()

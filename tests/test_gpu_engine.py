@@ -203,14 +203,19 @@ def test_cmnd_in_the_frame_kernel_equals_the_walk_in_pyin_obs(sr, hop, monkeypat
     clips = [signals.guitar_clip(2.0 + 0.37 * i, sr=sr, seed=20 + i) for i in range(5)]
     clips += [np.zeros(0, np.float32), (0.1 * rng.standard_normal(hop // 2)).astype(np.float32), signals.guitar_clip(1.0, sr=sr, seed=31, noise_dbfs=-10.0)]
     outs = []
-    for knob in ("1", "0"):
-        monkeypatch.setenv("AEGIS_CMND_IN_FRAME", knob)
+    # what runs (CMND and trough lists from the frame kernel), the round-3 path (CMND from the frame kernel, troughs found by
+    # pyin_obs_kernel: AEGIS_TROUGHS_IN_FRAME=0), and everything in pyin_obs_kernel
+    for cmnd, troughs in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("AEGIS_CMND_IN_FRAME", cmnd)
+        monkeypatch.setenv("AEGIS_TROUGHS_IN_FRAME", troughs)
         h = _lib.Handle(sample_rate=sr, hop_length=hop)
         outs.append(h.analyze_batch(clips, stages=_lib.STAGE_PYIN))
         h.close()
-    for a, b in zip(*outs):
-        for k in ("f0", "voiced_flag", "voiced_prob"):
-            np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+    monkeypatch.delenv("AEGIS_TROUGHS_IN_FRAME")
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            for k in ("f0", "voiced_flag", "voiced_prob"):
+                np.testing.assert_array_equal(a[k], b[k], err_msg=k)
     f0, vf, vp = opyin.pyin(clips[1], sr=sr, hop_length=hop)
     np.testing.assert_array_equal(outs[0][1]["voiced_flag"], vf)
     np.testing.assert_array_equal(outs[0][1]["voiced_prob"], vp)
@@ -631,6 +636,22 @@ def test_dense_pass_of_short_ragged_clips(monkeypatch):
     lens = np.array([len(c) for c in clips])
     short = [int(i) for i in np.argsort(lens)[2:5]]
     _check_throughput_pass(monkeypatch, clips, [17, 18, 0, 255, int(np.argmax(lens))], short + [18], "256 short ragged clips")
+
+
+def test_a_process_holding_a_live_handle_exits_after_an_exception():
+    """gpurun_out/call53.log (round 3): a script died with an AttributeError while a Handle was alive -- 22 050 Hz, profiling
+    on, one host-buffer analyze_batch of a clip long enough for time chunks (the CU-masked streams exist) -- and then sat
+    until `timeout` killed it: Handle.__del__ -> aegis_destroy -> hipStreamDestroy of the CU-masked Viterbi stream never
+    returned.  The same script must now end with the exception's exit code within seconds, through
+    the atexit hook (`raise`) and through an explicit `del` in a live interpreter (`del`)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for variant in ("raise", "del"):
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "exit_hang_probe.py"), variant, "22050", "1", "80", "1"],
+                           capture_output=True, text=True, timeout=120)
+        assert r.returncode == 1, (variant, r.returncode, r.stderr[-400:])
+        assert "chunks" in r.stdout and "Error" in r.stderr and "end of script" not in r.stdout, (variant, r.stdout, r.stderr[-400:])
 
 
 def test_graft_entry_smoke():

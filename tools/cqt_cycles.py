@@ -5,7 +5,14 @@ from tools import signals
 clips = [signals.polyphonic_clip(30.0, seed=100 + i % 4) for i in range(64)]
 h = _lib.Handle(); h.cqt(clips[:2]); h.cqt(clips)
 v = h.debug_fetch("cqt_cycles")
-passes = {1: 32, 2: 22, 3: 14, 4: 8, 5: 4, 6: 4, 7: 4, 11: 4}     # 256-tap passes per active-tile count (CQT-84)
+import numpy as np
+r = 2.0 ** (1 / 12); alpha = (r * r - 1) / (r * r + 1)
+half = [(int(-np.floor(-((1.0 / alpha) * 44100 / (32.70319566257483 * 2.0 ** (8 * T / 12))) / 2)) + 1 + 511) // 512 * 512 for T in range(11)]
+npass = 2 * half[0] // 256
+passes = {}                                                        # 256-tap passes per active-tile count (CQT-84), as build_cqt_bank lays them out
+for q in range(npass):
+    na = sum(1 for h_ in half if (half[0] - h_) // 256 <= min(q, npass - 1 - q))
+    passes[na] = passes.get(na, 0) + 1
 print("prologue", int(v[0]), "barrier", int(v[12]), "epilogue", int(v[13]), "total", int(v[14]))
 for k in range(1, 12):
     if v[k]:
