@@ -126,7 +126,7 @@ def load():
 
 
 _TABLE_DTYPES = {"mel_dense": np.float32}
-_DEBUG_DTYPES = {"persistent_fallbacks": np.int64, "obs_cycles": np.int64, "cqt_cycles": np.int64, "viterbi_cycles": np.int64, "viterbi_spans": np.int64, "frame_cycles": np.int64, "states": np.int32, "melpow": np.float32}
+_DEBUG_DTYPES = {"persistent_fallbacks": np.int64, "obs_cycles": np.int64, "cqt_cycles": np.int64, "viterbi_cycles": np.int64, "viterbi_spans": np.int64, "split_verify": np.int64, "split_flags": np.int64, "seg_lock": np.int64, "frame_cycles": np.int64, "states": np.int32, "melpow": np.float32}
 
 
 _live_handles = weakref.WeakSet()

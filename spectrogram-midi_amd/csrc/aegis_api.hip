@@ -41,6 +41,8 @@ struct DevBuf {
 struct PassMeta {   // host copies kept alive until the stream has consumed them
     std::vector<int64_t> sample_off, sample_len, out_off, frame_off, chunk_off, sel_off, chunk_lo, clip_tb;
     std::vector<int32_t> order;
+    std::vector<int64_t> seg64;     // time-split pass: seg_f0 | seg_ch0
+    std::vector<int32_t> seg32;     // seg_T | seg_store | seg_prev | seg_clip | clip_seg0 | seg_order | lock_order
 };
 
 }  // namespace
@@ -79,6 +81,7 @@ struct aegis_handle {
     struct Work {
         DevBuf dfn, yin, logobs, logunv, obs_seg, ptr, cmap, chunk_off, bnd, states, melpow, clipmax, rake_raw;
         DevBuf sample_off, sample_len, out_off, frame_off, order, sel_off, vstate, chunk_lo, chunk_flag, clip_tb;
+        DevBuf seg64, seg32, seg_col, seg_map, seg_i32, colhist, colG, colkg, clip_flag, flag_order, tube_buf, tube_at, tube_count;    // time-split passes
     } work[2];
     int last_work = 0;
     DevBuf vstats, rk_raw, abort_flag, finite_flag;
@@ -99,6 +102,16 @@ struct aegis_handle {
     std::vector<PassMeta> metas;
     // last pass geometry for aegis_debug_fetch
     int64_t last_frames = 0;
+    // time-split passes (viterbi.hip): AEGIS_TIME_SPLIT=<steps per segment> forces them, 0 turns them off, unset = when a pass
+    // is bound by the recurrence of its longest clip
+    int64_t split_seglen = -1;                // -1: automatic
+    int split_warmup = 128;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary
+    struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; };
+    int split_cooldown = 0;                   // automatic mode: calls left without time-split passes after one that did not pay (clips redone sequentially)
+    std::vector<SplitCheck> split_checks;     // split passes of the call in flight: their clip flags are read after the synchronisation
+    int64_t split_stats[4] = {0, 0, 0, 0};    // since create: split passes, segments, clips flagged for the sequential kernel, lock-on runs that never locked
+    int last_split_segments = 0;
+    std::vector<int64_t> last_split_flags;   // per clip of the call's last split pass (pass order: longest first): the verification's verdict bits
     int last_passes = 0, last_chunks = 0, last_dense = 0, last_proportional = 0, last_balanced = 0, last_persistent = 0;   // of the last call (its last pass)
     // profiling
     bool profiling = false;
@@ -305,6 +318,8 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_DEBUG_STAGES")) h->debug_stages = (e[0] == '1');
     if (const char *e = std::getenv("AEGIS_CMND_IN_FRAME")) h->cmnd_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_TROUGHS_IN_FRAME")) h->troughs_off = (e[0] == '0');
+    if (const char *e = std::getenv("AEGIS_TIME_SPLIT")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_seglen = v / kViterbiChunk * kViterbiChunk; }
+    if (const char *e = std::getenv("AEGIS_SPLIT_WARMUP")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_warmup = (int)(v / kViterbiChunk * kViterbiChunk); }
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_BALANCED_CHUNK")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0 && v % kViterbiChunk == 0) h->balanced_chunk = v; }
@@ -438,7 +453,8 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (auto &w : h->work)
         for (DevBuf *b : {&w.dfn, &w.yin, &w.logobs, &w.logunv, &w.obs_seg, &w.ptr, &w.cmap, &w.chunk_off, &w.bnd, &w.states, &w.melpow,
                           &w.clipmax, &w.rake_raw, &w.sample_off, &w.sample_len, &w.out_off, &w.frame_off, &w.order, &w.sel_off,
-                          &w.vstate, &w.chunk_lo, &w.chunk_flag, &w.clip_tb})
+                          &w.vstate, &w.chunk_lo, &w.chunk_flag, &w.clip_tb, &w.seg64, &w.seg32, &w.seg_col, &w.seg_map, &w.seg_i32,
+                          &w.colhist, &w.colG, &w.colkg, &w.clip_flag, &w.flag_order, &w.tube_buf, &w.tube_at, &w.tube_count})
             free_buf(*b);
     T("free staging");
     for (DevBuf *b : {&h->vstats, &h->rk_raw, &h->abort_flag, &h->finite_flag, &h->t_x, &h->t_off, &h->t_a, &h->t_b, &h->t_c, &h->t_d, &h->t_e,
@@ -553,6 +569,45 @@ static int finite_result(aegis_handle *h, uint32_t opts, const int64_t *sample_o
     return AEGIS_ERR_INVALID;
 }
 
+// After the synchronisation behind time-split passes: the clips whose decode the verification kernel could not certify (or
+// whose lock-on run never met the speculative run) are decoded again by the sequential kernel, and the pass is decoded into
+// the outputs once more.  Rare (a near-tie on the decoded path that involves a voiced state; a boundary inside a long
+// stretch without a voiced note).
+static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
+    for (auto &sc : h->split_checks) {
+        std::vector<uint32_t> flags((size_t)sc.nc);
+        HIPCHK(h, hipMemcpy(flags.data(), sc.p.clip_flag, (size_t)sc.nc * 4, hipMemcpyDeviceToHost));
+        std::vector<int32_t> redo;
+        h->last_split_flags.assign(flags.begin(), flags.end());
+        for (int i = 0; i < sc.nc; ++i)
+            if (flags[i]) { redo.push_back(i); if (flags[i] & 1u) ++h->split_stats[3]; }
+        if (redo.empty()) continue;
+        h->split_stats[2] += (int64_t)redo.size();
+        if (sc.automatic) {
+            // the redo is sequential and comes on top of the split pass: when it costs more than a quarter of what the pass
+            // would have taken sequentially (material without voiced notes never locks on and keeps its tubes open: noise,
+            // silence), the next 32 calls of this handle plan their passes sequentially
+            std::vector<int64_t> fo((size_t)sc.nc + 1);
+            HIPCHK(h, hipMemcpy(fo.data(), sc.p.frame_off, ((size_t)sc.nc + 1) * 8, hipMemcpyDeviceToHost));
+            int64_t redoF = 0;
+            for (int i : redo) redoF = std::max(redoF, fo[i + 1] - fo[i]);
+            if ((double)redoF * (t.half_width == 25 ? 3.1e-6 : 7.3e-6) > 0.25 * sc.t_seq) h->split_cooldown = 32;
+        }
+        aegis_handle::Work &w = h->work[sc.work];
+        HIPCHK(h, hipMemcpy(w.flag_order.p, redo.data(), redo.size() * 4, hipMemcpyHostToDevice));
+        PassParams q = sc.p;
+        q.order = static_cast<const int32_t *>(w.flag_order.p);
+        q.n_clips = (int32_t)redo.size();
+        q.vt_begin = 0; q.vt_end = INT64_MAX; q.clip_t0 = nullptr; q.clip_t1 = nullptr; q.chunk_flag = nullptr; q.dense = 0;
+        hipError_t ve = launch_viterbi(q, h->dt, t.log_trans_band.data(), s);
+        if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+        launch_decode(sc.p, h->dt, s);
+        HIPCHK(h, hipStreamSynchronize(s));
+    }
+    h->split_checks.clear();
+    return AEGIS_OK;
+}
+
 static aegis_handle::SplitSet *split_streams(aegis_handle *h, int n_clips) {
     if (n_clips > h->split_limit || h->split_limit <= 0) return nullptr;
     if (h->n_cus != 256) return nullptr;      // the masks below are laid out for the 256 CUs of an un-partitioned MI355X
@@ -619,6 +674,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     }
     // host metadata from earlier calls is no longer referenced once the stream drained
     if (!h->metas.empty()) { HIPCHK(h, hipStreamSynchronize(s)); h->metas.clear(); }
+    h->split_checks.clear();
     if (h->profiling) { for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); } h->events.clear(); }
 
     // vision.py:23-25
@@ -687,7 +743,61 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Viterbi launch that waits for a flag per chunk (64 clips x 180 s: 59.5 -> 50.8 ms).  With fewer clips the pass is
         // Viterbi-bound and the gain is the launches and the head (48 clips: 52.0 -> 50.2 ms, 16: 50.2 -> 50.0, 8: 49.5
         // -> 49.8), hence the lower limit; unpartitioned passes lose with small chunks.
-        const bool balanced = py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
+        // ---- time-split pass? (viterbi.hip "Time-split Viterbi") ------------------------------------------------
+        // The Viterbi recurrence keeps one compute unit per clip for (frames of the clip) x 3.1 us; the rest of the path
+        // costs ~43 ns per frame of the whole chip.  A pass whose longest clip outlasts the work of the whole pass cuts
+        // its clips into segments that run concurrently (blocking calls on the handle's own stream only: the clips that
+        // cannot be certified are redone after the call's synchronisation).
+        int64_t seglen = 0;
+        bool split_auto = false;
+        if (py && !stream_v && sync && nc < 256 && h->split_seglen != 0 && viterbi_split_applies(base_params(t), h->dt)) {
+            if (h->split_seglen > 0) seglen = h->split_seglen;
+            else if (h->split_cooldown > 0) --h->split_cooldown;
+            else {
+                // automatic: when the estimate says so.  Sequential pass: the longest clip's recurrence, or the pass's whole
+                // work if that is more (they overlap); split pass: the frame stage first (3/4 of the work, not overlapped),
+                // then one segment + warm-up + a typical lock-on tail, stitch and verification.
+                const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, work = (double)fp * 43e-9;
+                const int64_t sl = std::max<int64_t>(768, ((fp - nc) / std::max(1, h->n_cus) + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                const double t_seq = std::max((double)maxF * step, work);
+                const double t_split = 0.75 * work + (double)(sl + h->split_warmup + 600) * step + 2.5e-3;
+                if (t_split < 0.8 * t_seq) { seglen = sl; split_auto = true; }
+            }
+        }
+        const bool tsplit = seglen > 0;
+        int n_seg = 0, n_lock = 0, tube_cap = 0;
+        if (tsplit) {
+            const int L = h->split_warmup;
+            std::vector<int64_t> sf0, sch0;
+            std::vector<int32_t> sT, sst, sprev, sclip, cseg0(nc + 1, 0);
+            for (int i = 0; i < nc; ++i) {
+                const int64_t Fc = frames[pc[i]], steps = Fc - 1;
+                const int ns = (int)std::max<int64_t>(1, (steps + seglen / 2) / seglen);
+                cseg0[i] = n_seg;
+                int64_t mprev = 0;
+                for (int k = 0; k < ns; ++k) {
+                    // boundaries on back-pointer chunk boundaries (multiples of 16); the last segment ends at the last frame
+                    const int64_t mk = k == 0 ? 0 : std::max<int64_t>(mprev + kViterbiChunk, (steps * k / ns) / kViterbiChunk * kViterbiChunk);
+                    const int64_t mnext = k == ns - 1 ? Fc - 1 : std::max<int64_t>(mk + kViterbiChunk, (steps * (k + 1) / ns) / kViterbiChunk * kViterbiChunk);
+                    const int64_t wk = k == 0 ? 0 : std::max<int64_t>(0, mk - L);
+                    sf0.push_back(m.frame_off[i] + wk);
+                    sch0.push_back(m.chunk_off[i] + wk / kViterbiChunk);
+                    sT.push_back((int32_t)(mnext - wk + 1));
+                    sst.push_back((int32_t)(mk - wk));
+                    sprev.push_back(k == 0 ? -1 : n_seg - 1);
+                    sclip.push_back(i);
+                    mprev = mk;
+                    ++n_seg;
+                }
+            }
+            cseg0[nc] = n_seg;
+            m.seg64 = sf0; m.seg64.insert(m.seg64.end(), sch0.begin(), sch0.end());
+            m.seg32.clear();
+            for (auto *v : {&sT, &sst, &sprev, &sclip, &cseg0}) m.seg32.insert(m.seg32.end(), v->begin(), v->end());
+            for (int k = 0; k < n_seg; ++k) m.seg32.push_back(k);                       // seg_order
+            for (int k = 0; k < n_seg; ++k) if (sprev[k] >= 0) { m.seg32.push_back(k); ++n_lock; }      // lock_order
+        }
+        const bool balanced = !tsplit && py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
                               h->split_limit > 0 && nc <= h->split_limit && nc <= 128;
         // (a persistent Viterbi launch pays nothing per chunk: half the chunk size, 54.3 -> 52.0 ms).  The size is stated for
         // 64 clips and scaled so that a chunk's observation kernel is ONE full round of workgroups on the frame stage's
@@ -723,7 +833,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 for (size_t i = ramp.size(); i-- > 1;) { b += ramp[i]; if (b < maxF) cb.push_back(b); }
             } else
             for (int64_t b = 1 + std::max<int64_t>(kViterbiChunk, kTimeChunk - kViterbiChunk); b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
-        } else if (py && maxF > kTimeChunk + kTimeChunk / 2) {
+        } else if (py && !tsplit && maxF > kTimeChunk + kTimeChunk / 2) {      // (a time-split pass: the whole frame stage, then all segments at once)
             int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
             while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
@@ -742,7 +852,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // carries every clip and all of them finish with the last chunk.  The results do not depend on the cut.
         // Throughput passes (a Viterbi workgroup for every CU and more): the register-capped Viterbi build and four-wave
         // observation workgroups (viterbi.hip); AEGIS_DENSE=0 turns it off, =1 forces it for every unbalanced pass (tests).
-        const bool dense = py && !balanced && viterbi_band_applies(base_params(t), h->dt) && t.half_width == 25 &&
+        const bool dense = py && !balanced && !tsplit && viterbi_band_applies(base_params(t), h->dt) && t.half_width == 25 &&
                            (h->dense_mode == 1 || (h->dense_mode < 0 && nc >= 256));
         bool proportional = false;
         // (not for a pass fed from host memory: it is bound by the pageable copies, and a short clip's proportional chunk is a
@@ -822,6 +932,14 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             ENS(states, fp * 4); ENS(vstate, (size_t)nc * S * 8);
             ENS(chunk_lo, (size_t)nk * 8); ENS(chunk_flag, (size_t)nk * 4);
             if (proportional) ENS(clip_tb, (size_t)(nk + 1) * nc * 8);
+            if (tsplit) {
+                ENS(seg64, m.seg64.size() * 8); ENS(seg32, m.seg32.size() * 4);
+                ENS(seg_col, (size_t)n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, (size_t)n_seg * 3 * 4);
+                ENS(colhist, (size_t)fp * S * 8); ENS(colG, (size_t)fp * 8); ENS(colkg, (size_t)fp * 4); ENS(clip_flag, (size_t)nc * 4);
+                ENS(flag_order, (size_t)nc * 4);
+                tube_cap = (int)std::max<int64_t>(4096, fp / 128);
+                ENS(tube_buf, (size_t)tube_cap * viterbi_tube_record_ints() * 4); ENS(tube_at, (size_t)fp * 4); ENS(tube_count, 4);
+            }
         }
         if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
 #undef ENS
@@ -834,6 +952,14 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipMemcpyAsync(w.sel_off.p, m.sel_off.data(), (size_t)nk * (nc + 1) * 8, hipMemcpyHostToDevice, fa));
         if (proportional) HIPCHK(h, hipMemcpyAsync(w.clip_tb.p, m.clip_tb.data(), (size_t)(nk + 1) * nc * 8, hipMemcpyHostToDevice, fa));
         if (stages & AEGIS_STAGE_MEL) HIPCHK(h, hipMemsetAsync(w.clipmax.p, 0, nc * 4, fa));
+        if (tsplit) {
+            HIPCHK(h, hipMemcpyAsync(w.seg64.p, m.seg64.data(), m.seg64.size() * 8, hipMemcpyHostToDevice, fa));
+            HIPCHK(h, hipMemcpyAsync(w.seg32.p, m.seg32.data(), m.seg32.size() * 4, hipMemcpyHostToDevice, fa));
+            HIPCHK(h, hipMemsetAsync(w.seg_i32.p, 0, (size_t)n_seg * 3 * 4, fa));       // seg_lock = 0 for the segments without a lock-on run
+            HIPCHK(h, hipMemsetAsync(w.clip_flag.p, 0, (size_t)nc * 4, fa));
+            HIPCHK(h, hipMemsetAsync(w.tube_at.p, 0, (size_t)fp * 4, fa));
+            HIPCHK(h, hipMemsetAsync(w.tube_count.p, 0, 4, fa));
+        }
         PassParams p = base_params(t);
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
         // observation kernel, instead of being launched per chunk (40 launches of 45 us each at 64 clips x 180 s, and the
@@ -890,6 +1016,23 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         p.rake_ratio = rake_sensitivity;
         p.rake_min_frames = rake_min; p.rake_max_frames = rake_max;
         if (opts & AEGIS_OPT_F0_ZERO) p.f0_unvoiced = 0.0;
+        const int32_t *d_seg_order = nullptr, *d_lock_order = nullptr;
+        if (tsplit) {
+            const int64_t *g64 = static_cast<const int64_t *>(w.seg64.p);
+            const int32_t *g32 = static_cast<const int32_t *>(w.seg32.p);
+            p.seg_f0 = g64; p.seg_ch0 = g64 + n_seg;
+            p.seg_T = g32; p.seg_store = g32 + n_seg; p.seg_prev = g32 + 2 * n_seg; p.seg_clip = g32 + 3 * n_seg;
+            p.clip_seg0 = g32 + 4 * n_seg;
+            d_seg_order = g32 + 4 * n_seg + nc + 1; d_lock_order = d_seg_order + n_seg;
+            p.seg_col = static_cast<double *>(w.seg_col.p);
+            p.seg_map = static_cast<uint16_t *>(w.seg_map.p);
+            p.seg_kg = static_cast<int32_t *>(w.seg_i32.p); p.seg_lock = p.seg_kg + n_seg; p.seg_end = p.seg_kg + 2 * n_seg;
+            p.colhist = static_cast<double *>(w.colhist.p); p.colG = static_cast<double *>(w.colG.p); p.colkg = static_cast<int32_t *>(w.colkg.p);
+            p.clip_flag = static_cast<uint32_t *>(w.clip_flag.p);
+            p.tube_buf = static_cast<int32_t *>(w.tube_buf.p); p.tube_cap = tube_cap; p.tube_count = static_cast<uint32_t *>(w.tube_count.p);
+            p.tube_at = static_cast<int32_t *>(w.tube_at.p);
+            p.n_seg = n_seg;
+        }
 
         if (persistent) {
             p.chunk_flag = static_cast<const uint32_t *>(w.chunk_flag.p);
@@ -957,9 +1100,14 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0 + k], 0));
                 }
                 begin_event(h, "viterbi", sv);
-                hipError_t ve = launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
+                hipError_t ve = tsplit ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, d_lock_order, n_lock, sv)
+                                       : launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
                 end_event(h, sv);
                 if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+                if (tsplit) {
+                    h->split_checks.push_back({pass_index & 1, p, nc, split_auto, (double)maxF * (t.half_width == 25 ? 3.1e-6 : 7.3e-6)});
+                    ++h->split_stats[0]; h->split_stats[1] += n_seg;
+                }
             }
         }
         if (use_fb) {                    // the dB / rake finalisation needs every chunk's mel rows and clip maxima
@@ -977,6 +1125,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         done_recorded[pass_index & 1] = true;
         HIPCHK(h, hipGetLastError());
         h->last_frames = fp;
+        h->last_split_segments = tsplit ? n_seg : 0;
         h->last_chunks = nk; h->last_dense = dense ? 1 : 0; h->last_proportional = proportional ? 1 : 0;
         h->last_balanced = balanced ? 1 : 0; h->last_persistent = persistent ? 1 : 0;
         h->last_work = pass_index & 1;
@@ -993,6 +1142,11 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         HIPCHK(h, hipMemsetAsync(h->finite_flag.p, 0xff, 8, s));
         const int64_t lo = sample_offsets[0], hi = sample_offsets[n_clips];
         launch_finite_check(d_pcm + lo, hi - lo, static_cast<unsigned long long *>(h->finite_flag.p), s);
+    }
+    if (!h->split_checks.empty()) {         // (sync != 0: time-split passes are planned for blocking calls only)
+        HIPCHK(h, hipStreamSynchronize(s));
+        int rc = split_check(h, t, s);
+        if (rc != AEGIS_OK) return rc;
     }
     if (sync == 1) {
         HIPCHK(h, hipStreamSynchronize(s));
@@ -1823,6 +1977,11 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "obs_stride") return h->obs_stride;
     if (n == "last_frames") return h->last_frames;
     if (n == "last_passes") return h->last_passes;
+    if (n == "last_split_segments") return h->last_split_segments;
+    if (n == "split_passes") return h->split_stats[0];
+    if (n == "split_segments") return h->split_stats[1];
+    if (n == "split_flagged_clips") return h->split_stats[2];
+    if (n == "split_unlocked_clips") return h->split_stats[3];
     if (n == "last_chunks") return h->last_chunks;
     if (n == "last_dense") return h->last_dense;
     if (n == "last_proportional") return h->last_proportional;
@@ -1935,6 +2094,36 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
             std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 24) * 8);
         }
         return 24;
+    }
+    else if (n == "seg_lock") {           // lock-on run lengths of the last time-split pass, one per segment (0: first of its clip, -1: never met)
+        if (h->device < 0 || h->last_split_segments <= 0) return 0;
+        const int ns = h->last_split_segments;
+        if (dst && cap > 0) {
+            std::vector<int32_t> v((size_t)ns), st((size_t)ns);
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            const aegis_handle::Work &lw = h->work[h->last_work];
+            HIPCHK(h, hipMemcpy(v.data(), static_cast<const int32_t *>(lw.seg_i32.p) + ns, (size_t)ns * 4, hipMemcpyDeviceToHost));
+            HIPCHK(h, hipMemcpy(st.data(), static_cast<const int32_t *>(lw.seg32.p) + ns, (size_t)ns * 4, hipMemcpyDeviceToHost));
+            int64_t *o = static_cast<int64_t *>(dst);
+            for (int i = 0; i < std::min<int64_t>(cap, ns); ++i) o[i] = v[i] > 0 ? v[i] - st[i] : v[i];
+        }
+        return ns;
+    }
+    else if (n == "split_flags") {
+        if (dst && cap > 0) std::memcpy(dst, h->last_split_flags.data(), (size_t)std::min<int64_t>(cap, (int64_t)h->last_split_flags.size()) * 8);
+        return (int64_t)h->last_split_flags.size();
+    }
+    else if (n == "split_verify") {
+        if (h->device < 0) return AEGIS_ERR_INVALID;
+        if (dst && cap > 0) {                     // reading resets the counters
+            long long v[16];
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipDeviceSynchronize());
+            HIPCHK(h, viterbi_verify_fetch(v, true));
+            std::memcpy(dst, v, (size_t)std::min<int64_t>(cap, 16) * 8);
+        }
+        return 16;
     }
     else if (n == "viterbi_cycles") {
         if (h->device < 0) return AEGIS_ERR_INVALID;

@@ -86,6 +86,29 @@ struct PassParams {
     uint32_t chunk_gen;
     uint32_t *abort_flag;
     uint64_t wait_ticks;         // bound of one chunk wait in 100 MHz wall-clock ticks (0: 1.5 s)
+    // Time-split Viterbi (viterbi_band_split_kernel and the stitch / verification kernels, viterbi.hip): a clip is cut into
+    // segments that run concurrently, one workgroup each.  Segment s covers the pass's workspace frames seg_f0[s] ..
+    // seg_f0[s] + seg_T[s] - 1 (local steps 1 .. seg_T - 1); the first seg_store[s] steps are a warm-up from a guessed
+    // column whose results are not kept; local frame seg_store[s] is the boundary it shares with segment seg_prev[s].
+    const int64_t *seg_f0;       // [n_seg]
+    const int32_t *seg_T;        // [n_seg]
+    const int64_t *seg_ch0;      // [n_seg] back-pointer chunk (of the pass) that holds local steps 1..16
+    const int32_t *seg_store;    // [n_seg]
+    const int32_t *seg_prev;     // [n_seg] the segment before it in its clip, -1 for a clip's first
+    const int32_t *seg_clip;     // [n_seg] its clip (index into the pass)
+    const int32_t *clip_seg0;    // [n_clips + 1] first segment of each clip
+    double *seg_col;             // [n_seg][2 n_bins] end column of the speculative run
+    int32_t *seg_kg;             // [n_seg] its arg-max
+    int32_t *seg_lock;           // [n_seg] local step at which the lock-on run met the speculative run, -1: it did not
+    int32_t *seg_end;            // [n_seg] decoded state at the segment's last frame (stitch)
+    uint16_t *seg_map;           // [n_seg][2 n_bins] state at the segment's last frame -> state at its boundary frame
+    double *colhist;             // [F][2 n_bins] the column of every stored frame (lock-on comparison, verification)
+    double *colG; int32_t *colkg;   // [F] its maximum and arg-max
+    int32_t *tube_buf; int32_t tube_cap; uint32_t *tube_count;   // records of the verification kernel's tubes (viterbi.hip kTubeRec ints each)
+    int32_t *tube_at;            // [F] (depth << 24) | (record + 1) of the deepest tube whose bottom (collapse) frame this is, 0: none
+    uint32_t *clip_flag;         // [n_clips] != 0: the clip's decode could not be certified, the sequential kernel must redo it
+    int32_t split_phase;         // 1: speculative runs, 2: lock-on runs
+    int32_t n_seg;
     // workspace (strides in elements)
     double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period; with
                                          //                   cmnd_in_frame the entries tau >= min_period hold the CMND instead
@@ -125,6 +148,13 @@ bool frame_cmnd_supported(int max_period);
 int trough_row_doubles_host(int n_lags);    // doubles of a dfn row that holds a frame's trough list (PassParams::troughs)   // the frame kernel's LDS holds the CMND rows of a workgroup's frames (PassParams::cmnd_in_frame)
 void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
+// time-split pass: speculative runs (grid = segments), lock-on runs (grid = segments that have a predecessor, listed in
+// lock_order), stitch + back-trace, verification; seg_order (device) lists 0..n_seg-1
+hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order,
+                                const int32_t *lock_order, int n_lock, hipStream_t s);
+bool viterbi_split_applies(const PassParams &p, const DevTables &t);
+hipError_t viterbi_verify_fetch(long long *dst, bool reset);
+int viterbi_tube_record_ints();   // counters of the time-split verification kernel (viterbi.hip g_verify_dbg)
 bool viterbi_band_applies(const PassParams &p, const DevTables &t);   // the band-specialised kernels (the ones that can wait for chunk flags) take this geometry
 void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s);
 void launch_decode(const PassParams &p, const DevTables &t, hipStream_t s);

@@ -705,50 +705,51 @@ __global__ __launch_bounds__(256, 2) void frame_yin_kernel(PassParams p, DevTabl
         // ---- troughs of the CMND, compacted (round 4).  pyin_obs_kernel used to load the 495-lag CMND row of every frame
         // from memory and spend a sixth of its time finding the local minima; here the row is in LDS anyway, so every wave
         // takes the frames wid, wid + 4, ... of the workgroup, finds the troughs exactly as pyin_obs_kernel does (util.localmin
-        // plus the special first element, contiguous lag chunk per lane, ballot-free prefix scan) and writes, in ascending lag
+        // plus the special first element) and writes, in ascending lag
         // order, each trough's CMND value, its parabolic shift (pitch.py::_parabolic_interpolation: a function of the three
         // CMND values around it) and its lag index: a few hundred bytes per frame instead of the 4 KB row, and the
         // observation kernel starts at the threshold prior.
         if (troughs) {
             __syncthreads();
-            const int nl = p.n_lags, KM = trough_km(nl), CH = (nl + 63) >> 6;
+            const int nl = p.n_lags, KM = trough_km(nl), NR = (nl + 63) >> 6;
+            const unsigned long long below = (1ull << lane) - 1ull;
             for (int i = wid; i < nfr; i += 4) {
                 if (fr[i] < 0) continue;                                  // (uniform)
                 const double *__restrict__ y = row_of(i) + minp;
-                unsigned mask = 0;
-                int cnt = 0;
-                for (int r = 0; r < CH; ++r) {
-                    const int k = lane * CH + r;
-                    if (k < nl) {
-                        const double yi = y[k];
-                        bool tr;
-                        if (k == 0) tr = yi < y[1];
-                        else if (k == nl - 1) tr = yi < y[k - 1];
-                        else tr = (yi < y[k - 1]) && (yi <= y[k + 1]);
-                        if (tr) { mask |= 1u << r; ++cnt; }
-                    }
-                }
-                const int incl = wave_incl_scan(cnt, lane);
-                const int K = __shfl(incl, 63);
                 double *__restrict__ trow = p.dfn + fr[i] * (int64_t)p.lag_stride;
                 int16_t *__restrict__ tiv = reinterpret_cast<int16_t *>(trow + 8 + 2 * KM);
-                if (lane == 0) trow[0] = __longlong_as_double((long long)K);
-                int pos = incl - cnt;
-                for (int r = 0; r < CH; ++r)
-                    if (mask & (1u << r)) {
-                        const int k = lane * CH + r;
+                // lag k = 64 r + lane: consecutive lanes read consecutive doubles (a contiguous chunk per lane, as
+                // pyin_obs_kernel walks the row, puts 32 lanes on one pair of banks); ascending lag order = round after
+                // round, lane after lane, so a round's ballot and a population count place its troughs
+                int K = 0;
+                for (int r = 0; r < NR; ++r) {
+                    const int k = 64 * r + lane;
+                    bool tr = false;
+                    double ym = 0.0, y0 = 0.0, yp = 0.0;
+                    if (k < nl) {
+                        y0 = y[k];
+                        if (k > 0) ym = y[k - 1];
+                        if (k < nl - 1) yp = y[k + 1];
+                        if (k == 0) tr = y0 < yp;
+                        else if (k == nl - 1) tr = y0 < ym;
+                        else tr = (y0 < ym) && (y0 <= yp);
+                    }
+                    const unsigned long long m = __ballot(tr);
+                    if (tr) {
+                        const int pos = K + __popcll(m & below);
                         double shift = 0.0;
                         if (k > 0 && k < nl - 1) {
-                            const double ym = y[k - 1], y0 = y[k], yp = y[k + 1];
                             const double a = yp + ym - 2.0 * y0;
                             const double b = (yp - ym) / 2.0;
                             if (fabs(b) < fabs(a)) shift = -b / a;
                         }
-                        trow[8 + pos] = y[k];
+                        trow[8 + pos] = y0;
                         trow[8 + KM + pos] = shift;
                         tiv[pos] = (int16_t)k;
-                        ++pos;
                     }
+                    K += __popcll(m);
+                }
+                if (lane == 0) trow[0] = __longlong_as_double((long long)K);
             }
         }
     }

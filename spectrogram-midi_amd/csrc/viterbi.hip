@@ -331,6 +331,7 @@ __device__ unsigned long long g_vit_span[272];
 // with a workgroup on every CU (>= 256 clips) the observation kernel's four-wave workgroups then run ON the Viterbi's CUs,
 // in the issue slots its dependent chains leave empty, instead of waiting for a CU of their own (512-clip folder: 337 ->
 // 328 ms; 256 x 180 s: 160.5 -> 157.3).
+#define VIT_SPLIT 0
 template <int H, bool LT_LDS>
 __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTables tb, BandLT<H> blt) {
 #include "viterbi_band.inc"
@@ -338,6 +339,360 @@ __global__ __launch_bounds__(1024) void viterbi_band_kernel(PassParams p, DevTab
 template <int H, bool LT_LDS>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 5))) void viterbi_band_dense_kernel(PassParams p, DevTables tb, BandLT<H> blt) {
 #include "viterbi_band.inc"
+}
+#undef VIT_SPLIT
+// Third build of the body: one workgroup per SEGMENT of a clip (time-split passes, see the section below).
+#define VIT_SPLIT 1
+template <int H, bool LT_LDS>
+__global__ __launch_bounds__(1024) void viterbi_band_split_kernel(PassParams p, DevTables tb, BandLT<H> blt) {
+#include "viterbi_band.inc"
+}
+#undef VIT_SPLIT
+
+// ------------------------------------------------------------------------------------------
+// Time-split Viterbi (round 4).  The recurrence is sequential in time, one workgroup per clip: a pass with fewer clips
+// than compute units is bound by its longest clip (28 424 steps x 3.1 us = 88 ms for a 330 s clip, whatever else the
+// chip has to do).  A clip is therefore cut into segments that run CONCURRENTLY:
+//   1. speculative runs: segment k >= 1 starts `warm-up` frames before its boundary from a guessed column (the first-
+//      frame formula).  A max-plus recurrence forgets its start as soon as every state's best path runs through one
+//      state -- after any voiced note, within a few dozen frames -- and from there on its columns equal the true ones up
+//      to ONE additive constant, so its decisions are the true ones;
+//   2. lock-on runs: segment k starts again at its boundary, now from the END column of segment k - 1, and runs until its
+//      column differs from the stored speculative column by a constant (spread of the differences <= sigma): usually at
+//      the first check, 16 steps in.  Its pointers replace the speculative ones up to there;
+//   3. stitch: per-segment pointer maps (state at the segment's end -> state at its boundary), composed per clip from
+//      the last segment's arg-max down, then the usual back-trace inside every segment, all in parallel;
+//   4. verification: float64 sums are not translation invariant, so a decision of the hybrid run can differ from the
+//      sequential run's where two candidates are closer than the accumulated rounding bound (and they are, exactly or
+//      nearly: two steps of an unvoiced walk commute, (X + k[a]) + k[c] against (X + k[c]) + k[a]).  Every state a path
+//      within that bound of the optimum can occupy is enumerated backwards from each such decision on the decoded path
+//      (the "tube"), until the tube collapses onto the path again: the decode is certified when, at every frame, the tube
+//      holds unvoiced states only or one single state -- then every near-optimal path, the sequential run's included, has
+//      the same voiced flags and the same voiced bins.  A clip that cannot be certified (or whose segment never locked on)
+//      is flagged and redone by the sequential kernel.
+// Outputs are therefore those of the sequential kernel by proof, not by luck; the unvoiced BIN of an unvoiced frame, which
+// no output carries, may differ.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void viterbi_segmap_kernel(PassParams p) {
+    constexpr int C = kViterbiChunk;
+    const int sg = blockIdx.x, S = 2 * p.n_bins, j = threadIdx.x;
+    if (j >= S) return;
+    const int T = p.seg_T[sg], st = p.seg_store[sg];
+    const uint16_t *__restrict__ cmap = p.cmap + p.seg_ch0[sg] * S;
+    int s = j;
+    if (T - 1 > st)
+        for (int cc = (T - 2) / C; cc >= st / C; --cc) s = cmap[(int64_t)cc * S + s];
+    p.seg_map[(int64_t)sg * S + j] = (uint16_t)s;
+}
+__global__ __launch_bounds__(64) void viterbi_stitch_kernel(PassParams p) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= p.n_clips) return;
+    const int S = 2 * p.n_bins, a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
+    bool bad = false;
+    for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] < 0;
+    int e = p.seg_kg[b - 1];
+    for (int k = b - 1; k >= a; --k) { p.seg_end[k] = e; e = p.seg_map[(int64_t)k * S + e]; }
+    p.states[p.frame_off[c]] = e;
+    if (bad) atomicOr(&p.clip_flag[c], 1u);
+}
+__global__ __launch_bounds__(256) void viterbi_segtrace_kernel(PassParams p) {
+    constexpr int C = kViterbiChunk;
+    const int sg = blockIdx.x, S = 2 * p.n_bins, tid = threadIdx.x;
+    const int T = p.seg_T[sg], st = p.seg_store[sg];
+    if (T - 1 <= st) return;
+    const int64_t f0 = p.seg_f0[sg], ch0 = p.seg_ch0[sg];
+    const uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
+    const uint16_t *__restrict__ ptr = p.ptr + f0 * S;
+    int32_t *__restrict__ bnd = p.bnd + ch0;
+    int32_t *__restrict__ states = p.states + f0;
+    const int cfirst = st / C, clast = (T - 2) / C;
+    if (tid == 0) {
+        int s = p.seg_end[sg];
+        for (int cc = clast; cc >= cfirst; --cc) { bnd[cc] = s; s = cmap[(int64_t)cc * S + s]; }
+    }
+    __threadfence();
+    __syncthreads();
+    for (int cc = cfirst + tid; cc <= clast; cc += blockDim.x) {
+        const int te = min((cc + 1) * C, T - 1);
+        int s = bnd[cc];
+        states[te] = s;
+        for (int tt = te; tt > cc * C + 1; --tt) { s = ptr[(int64_t)tt * S + s]; states[tt - 1] = s; }
+    }
+}
+
+// Verification and exact resolution (step 4 above).
+//
+// viterbi_verify_kernel: one wave per frame of a split clip behind its first boundary.  A decision of the decoded path is
+// AMBIGUOUS when more than one predecessor lies within the rounding bound of the best one; going backwards from the top of
+// a stretch of ambiguous decisions the wave enumerates every state a near-optimal path can occupy (the tube) until the
+// tube has collapsed onto the decoded path again, and RECORDS it: per frame the states of the tube.
+// viterbi_exact_kernel: one wave per clip walks the decoded path forwards from the first boundary -- where the column is
+// the sequential run's own, bit for bit -- and carries the sequential run's EXACT value of the path's state: outside the
+// tubes a chain of two float64 additions per frame (the value of a state is the rounded sum along its best path, and the
+// best path into a state of the decoded path is the decoded path wherever the decision is not ambiguous); inside a tube
+// the same recurrence over the tube's states only, with the sequential kernel's tie rule (lowest state index), which
+// yields the sequential run's own pointers there, and the path is re-traced through them.  What comes out is the
+// sequential run's path, unvoiced bins included -- or the clip is flagged (a tube deeper or wider than the record holds,
+// a tube that reaches the first boundary, an out-of-band candidate inside the bound, a segment that never locked on)
+// and the sequential kernel decodes it again.
+// g_verify_dbg: [0] -, [1] tubes opened, [2] tubes recorded, then the reasons a clip was flagged: [3] tube wider
+// than kTubeCap, [5] tube closed on another state than the decoded one, [6] tube open at the exact run, [7] deeper than
+// kTubeDepth, [8] largest depth recorded, [9] out-of-band candidate within the bound, [10] last column's maximum not unique
+// within the bound, [11] record buffer full, [12] tubes resolved by the exact walk, [13] of which changed the path
+constexpr int kTubeCap = 16, kTubeDepth = 48;
+constexpr int kTubeRec = 4 + (kTubeDepth + 1) * (1 + kTubeCap);      // ints of a record: clip, top frame, depth, -, then per depth n + states
+__device__ unsigned long long g_verify_dbg[16];
+
+// twice the distance the hybrid run's values can be from the sequential run's at workspace frame fr of a clip that starts
+// at frame fc and has nsp segments: one sigma per lock-on splice + two roundings per step and run
+__device__ __forceinline__ double split_bound(const PassParams &p, int64_t fr, int64_t fc, int nsp) {
+    const double g = fabs(p.colG[fr - 1]) + 1500.0;
+    return 2.0 * (nsp * (1e-7 + 1e-13 * g) + 4.5e-16 * (double)(fr - fc) * g);
+}
+// log-transition of (state si -> state sj) inside the band (|bin difference| <= H)
+__device__ __forceinline__ double split_lt(const PassParams &p, const DevTables &tb, int si, int sj) {
+    const int B = p.n_bins, H = p.half_width, W = p.width;
+    const int v = si >= B ? 1 : 0, v2 = sj >= B ? 1 : 0, bs = si - v * B, b2 = sj - v2 * B;
+    const int cl = bs < H ? bs : (bs > B - 1 - H ? bs - (B - 1 - 2 * H) : H);
+    return tb.lt_band[((size_t)(v * 2 + v2) * p.n_cls + cl) * W + (b2 - bs + H)];
+}
+// observation of state j at workspace frame fr, as the Viterbi kernels read it
+__device__ __forceinline__ double split_obs(const PassParams &p, int j, int64_t fr) {
+    const int B = p.n_bins;
+    if (j >= B) return p.logunv[fr];
+    return (p.obs_seg[fr] & (0x40000000 | (1 << (j >> 6)))) ? p.logobs[fr * (int64_t)p.obs_stride + j] : p.log_tiny;
+}
+
+__global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTables tb) {
+    constexpr int CAP = kTubeCap;
+    __shared__ int sets[4][2][CAP];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t f = (int64_t)blockIdx.x * 4 + w;
+    if (f >= p.n_frames) return;
+    const int B = p.n_bins, S = 2 * B, H = p.half_width, W = p.width, NC = p.n_cls;
+    int lo = 0, hi = p.n_clips;
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.frame_off[mid] <= f) lo = mid; else hi = mid; }
+    const int c = lo;
+    const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
+    if (b - a < 2) return;                                        // an unsplit clip is the sequential run itself
+    const int64_t fc = p.frame_off[c];
+    const int64_t fx = p.seg_f0[a + 1] + p.seg_store[a + 1];      // the first boundary: everything up to it is the exact run
+    if (f <= fx) return;
+    const int Tc = (int)(p.frame_off[c + 1] - fc), nsp = b - a;
+    int why = 0;
+    // predecessors of target j at frame fr within thr of the best one, appended to dst (deduplicated)
+    auto near_preds = [&](int j, int64_t fr, double thr, int *dst, int &n) {
+        const int v2 = j >= B ? 1 : 0, b2 = j - v2 * B;
+        const double *__restrict__ col = p.colhist + (fr - 1) * (int64_t)S;
+        const double G = p.colG[fr - 1];
+        const int kg = p.colkg[fr - 1];
+        double cand[4];                       // (voicing, round): up to 2 x 2 candidates per lane (W <= 128)
+        double best = -INFINITY;
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int d = lane + 64 * r, bs = b2 + d - H;
+                double cv = -INFINITY;
+                if (d < W && bs >= 0 && bs < B) {
+                    const int cl = bs < H ? bs : (bs > B - 1 - H ? bs - (B - 1 - 2 * H) : H);
+                    cv = col[v * B + bs] + tb.lt_band[((size_t)(v * 2 + v2) * NC + cl) * W + (W - 1 - d)];
+                }
+                cand[v * 2 + r] = cv;
+                best = fmax(best, cv);
+            }
+        const int bg = kg >= B ? kg - B : kg;
+        const bool oob = (bg > b2 ? bg - b2 : b2 - bg) > H;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) best = fmax(best, __shfl_xor(best, o));
+        if (oob && G + p.log_tiny >= best - thr) why = why ? why : 9;     // the out-of-band candidate in play: not handled
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                unsigned long long m = __ballot(cand[v * 2 + r] >= best - thr);
+                while (m) {
+                    const int l = (int)__ffsll((long long)m) - 1;
+                    m &= m - 1;
+                    const int sidx = v * B + b2 + l + 64 * r - H;
+                    bool have = false;
+                    for (int q = 0; q < n; ++q) have |= dst[q] == sidx;
+                    if (!have) { if (n < CAP) dst[n++] = sidx; else why = why ? why : 3; }
+                }
+            }
+    };
+    int *cur = sets[w][0], *nxt = sets[w][1];
+    cur[0] = p.states[f];
+    int n = 1;
+    if (f == fc + Tc - 1) {                   // the end of the path: every state of the last column within the bound of its maximum
+        const double *__restrict__ col = p.colhist + f * (int64_t)S;
+        const double thr = split_bound(p, f + 1, fc, nsp), G = p.colG[f];
+        n = 0;
+        for (int j0 = 0; j0 < S; j0 += 64) {
+            unsigned long long m = __ballot(j0 + lane < S && col[j0 + lane] >= G - thr);
+            while (m) { const int l = (int)__ffsll((long long)m) - 1; m &= m - 1; if (n < CAP) cur[n++] = j0 + l; else why = 3; }
+        }
+    } else {
+        // A tube opened by the decision above this one (frame f + 1) runs through this frame and below: only the TOP of a
+        // stretch of ambiguous decisions opens one
+        int m1 = 0, w0 = why;
+        near_preds(p.states[f + 1], f + 1, split_bound(p, f + 1, fc, nsp), nxt, m1);
+        if (why == w0 && m1 > 1) return;
+        why = w0;                             // (a failure up there is that wave's to report)
+        if (f + 1 == fc + Tc - 1) {           // ... and so does a last column whose maximum is not alone within the bound
+            const double *__restrict__ col = p.colhist + (f + 1) * (int64_t)S;
+            const double thr = split_bound(p, f + 2, fc, nsp), G = p.colG[f + 1];
+            int cnt = 0;
+            for (int j0 = 0; j0 < S; j0 += 64) cnt += __popcll(__ballot(j0 + lane < S && col[j0 + lane] >= G - thr));
+            if (cnt > 1) return;
+        }
+    }
+    int depth = 0;
+    int *rec = nullptr;
+    int64_t fr = f;
+    while (!why) {
+        int m = 0;
+        const double thr = split_bound(p, fr, fc, nsp);
+        for (int q = 0; q < n && !why; ++q) near_preds(cur[q], fr, thr, nxt, m);
+        if (why) break;
+        if (depth == 0) {
+            if (m == 1 && n == 1) { if (nxt[0] != p.states[fr - 1]) why = 5; break; }        // an unambiguous decision: the common case
+            // a tube opens: take a record
+            unsigned slot = 0;
+            if (lane == 0) slot = atomicAdd(p.tube_count, 1u);
+            slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
+            if (slot >= (unsigned)p.tube_cap) { why = 11; break; }
+            rec = p.tube_buf + (size_t)slot * kTubeRec;
+            if (lane == 0) { rec[0] = c; rec[1] = (int)(f - fc); rec[3] = (int)slot; rec[4] = n; for (int q = 0; q < n; ++q) rec[5 + q] = cur[q]; }
+        }
+        ++depth; --fr;
+        if (depth > kTubeDepth) { why = 7; break; }
+        if (lane == 0) { int *r = rec + 4 + depth * (1 + CAP); r[0] = m; for (int q = 0; q < m; ++q) r[1 + q] = nxt[q]; }
+        int *t2 = cur; cur = nxt; nxt = t2;
+        n = m;
+        if (n == 1) {                         // collapsed onto the decoded path again
+            if (cur[0] != p.states[fr]) why = 5;
+            break;
+        }
+        if (fr <= fx) break;                  // reached the first boundary with the tube still open: the exact column there holds every state's value
+    }
+    if (lane == 0 && (depth > 0 || why)) {   // (no per-frame counter: one address for a million waves is ~10 ns each)
+        if (depth > 0) atomicAdd(&g_verify_dbg[1], 1ull);
+        if (depth > 0 && !why) {
+            rec[2] = depth;
+            __threadfence();
+            // the tube's bottom frame: where the exact walk meets it.  Tubes nest (a decision inside an open tube may be ambiguous
+            // itself; its own tube is a subset of the outer one and ends at the same frame or above): the deepest one stays
+            atomicMax(&p.tube_at[fr], (depth << 24) | (rec[3] + 1));
+            atomicAdd(&g_verify_dbg[2], 1ull);
+            atomicMax(&g_verify_dbg[8], (unsigned long long)depth);
+        }
+        if (why) { atomicAdd(&g_verify_dbg[why], 1ull); atomicOr(&p.clip_flag[c], 2u); }
+    }
+}
+
+__global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTables tb) {
+    constexpr int CAP = kTubeCap;
+    __shared__ double xv[2][CAP];
+    __shared__ int ptrx[kTubeDepth + 1][CAP];
+    const int c = blockIdx.x, lane = threadIdx.x;
+    const int B = p.n_bins, S = 2 * B, H = p.half_width;
+    const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
+    if (b - a < 2) return;
+    if (__hip_atomic_load(&p.clip_flag[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;     // the sequential kernel redoes it anyway
+    const int64_t fc = p.frame_off[c], fx = p.seg_f0[a + 1] + p.seg_store[a + 1];
+    const int64_t fend = fc + (p.frame_off[c + 1] - fc) - 1;
+    int32_t *__restrict__ states = p.states;
+    double X = p.seg_col[(int64_t)a * S + states[fx]];         // the sequential run's own value of the path's state at the first boundary
+    int64_t t = fx;
+    int n_res = 0, n_chg = 0;
+    auto in_band = [&](int si, int sj) {
+        const int bi = si >= B ? si - B : si, bj = sj >= B ? sj - B : sj;
+        return (bi > bj ? bi - bj : bj - bi) <= H;
+    };
+    while (t < fend) {
+        // up to 64 frames ahead: the chain's operands in parallel, the tube markers of the frames the chain stands on
+        const int nblk = (int)min((int64_t)64, fend - t);
+        double al = 0.0, ol = 0.0;
+        int mark = 0;
+        if (lane < nblk) {
+            const int64_t fr = t + 1 + lane;
+            const int si = states[fr - 1], sj = states[fr];
+            al = in_band(si, sj) ? split_lt(p, tb, si, sj) : p.log_tiny;          // (out of band: the column arg-max's candidate)
+            ol = split_obs(p, sj, fr);
+            mark = p.tube_at[t + lane];
+        }
+        const unsigned long long mm = __ballot(mark != 0);
+        const int k0 = mm ? (int)__ffsll((long long)mm) - 1 : nblk;
+        for (int k = 0; k < k0; ++k) {
+            const double ak = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(al), k), __builtin_amdgcn_readlane(__double2loint(al), k));
+            const double ok = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ol), k), __builtin_amdgcn_readlane(__double2loint(ol), k));
+            X = ok + (X + ak);
+        }
+        t += k0;
+        if (!mm) continue;
+        // ---- a tube whose bottom is frame t: the recurrence over its states, bottom to top ----------------------------
+        const int slot = (__builtin_amdgcn_readlane(mark, k0) & 0xffffff) - 1;
+        const int *__restrict__ rec = p.tube_buf + (size_t)slot * kTubeRec;
+        const int D = rec[2];
+        const int64_t ttop = fc + rec[1];
+        {
+            const int *bs = rec + 4 + D * (1 + CAP);                   // the bottom set: one state, or several at the first boundary
+            if (lane < bs[0]) xv[0][lane] = bs[0] == 1 ? X : p.seg_col[(int64_t)a * S + bs[1 + lane]];
+        }
+        __syncthreads();
+        int pb = 0;
+        for (int d = D - 1; d >= 0; --d) {
+            const int64_t fr = ttop - d;
+            const int *cs = rec + 4 + d * (1 + CAP), *ps = rec + 4 + (d + 1) * (1 + CAP);
+            const int nc = cs[0], np = ps[0];
+            if (lane < nc) {
+                const int j = cs[1 + lane];
+                double best = -INFINITY;
+                int bs = 0x7fffffff, bidx = 0;
+                for (int i = 0; i < np; ++i) {
+                    const int si = ps[1 + i];
+                    if (!in_band(si, j)) continue;
+                    const double cand = xv[pb][i] + split_lt(p, tb, si, j);
+                    if (cand > best || (cand == best && si < bs)) { best = cand; bs = si; bidx = i; }
+                }
+                xv[pb ^ 1][lane] = split_obs(p, j, fr) + best;
+                ptrx[d][lane] = bidx;
+            }
+            __syncthreads();
+            pb ^= 1;
+        }
+        // the top: one state, or (last frame of the clip) the exact arg-max of the candidates, lowest state first
+        int top = 0;
+        {
+            const int *ts = rec + 4;
+            for (int q = 1; q < ts[0]; ++q)
+                if (xv[pb][q] > xv[pb][top] || (xv[pb][q] == xv[pb][top] && ts[1 + q] < ts[1 + top])) top = q;
+        }
+        X = xv[pb][top];
+        // the path through the tube by the exact pointers
+        if (lane == 0) {
+            bool changed = states[ttop] != rec[5 + top];
+            states[ttop] = rec[5 + top];
+            int idx = ptrx[0][top];
+            for (int d = 1; d <= D; ++d) {
+                const int st = rec[4 + d * (1 + CAP) + 1 + idx];
+                changed |= states[ttop - d] != st;
+                if (d == D) {
+                    // (a change here can only happen at the first boundary, where the bottom set holds several states: the path
+                    // enters the exact run in another state -- follow the exact run's own pointers down until the old path is met)
+                    int sx = st;
+                    int64_t tt = ttop - D;
+                    while (states[tt] != sx) { states[tt] = sx; if (tt == fc) break; sx = p.ptr[tt * (int64_t)S + sx]; --tt; }
+                } else states[ttop - d] = st;
+                if (d < D) idx = ptrx[d][idx];
+            }
+            n_res += 1; n_chg += changed ? 1 : 0;
+        }
+        __syncthreads();
+        t = ttop;
+    }
+    if (lane == 0 && n_res) { atomicAdd(&g_verify_dbg[12], (unsigned long long)n_res); atomicAdd(&g_verify_dbg[13], (unsigned long long)n_chg); }
 }
 
 #if defined(AEGIS_ABLATE) && (AEGIS_ABLATE & 512)
@@ -390,6 +745,12 @@ hipError_t viterbi_set_lds_limits() {
     e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_dense_kernel<25, true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_split_kernel<25, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    e = hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_split_kernel<50, true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
     return hipFuncSetAttribute(reinterpret_cast<const void *>(viterbi_band_kernel<50, true>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -408,6 +769,50 @@ __global__ void chunk_signal_kernel(uint32_t *flag, uint32_t gen) {
 }
 void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s) {
     hipLaunchKernelGGL(chunk_signal_kernel, dim3(1), dim3(1), 0, s, flag, gen);
+}
+
+static bool band_geometry(const PassParams &p);
+bool viterbi_split_applies(const PassParams &p, const DevTables &t) {
+    return viterbi_band_applies(p, t) && p.width <= 128;
+}
+template <int H>
+static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order,
+                                       const int32_t *lock_order, int n_lock, hipStream_t s) {
+    const int BP = (p.n_bins + 63) & ~63;
+    BandLT<H> blt;
+    for (int q = 0; q < 4; ++q) {
+        std::memcpy(blt.v[q], host_lt_band + ((size_t)q * p.n_cls + H) * p.width, sizeof(blt.v[q]));
+        blt.lmax[q] = *std::max_element(host_lt_band + (size_t)q * p.n_cls * p.width, host_lt_band + (size_t)(q + 1) * p.n_cls * p.width);
+    }
+    blt.lmax_all = *std::max_element(blt.lmax, blt.lmax + 4);
+    const size_t lds = viterbi_band_lds<H>(p, true) + 64 * 8;     // + the lock-on comparison's per-wave extremes
+    PassParams q = p;
+    q.split_phase = 1; q.order = seg_order;
+    hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)p.n_seg), dim3(2 * BP), lds, s, q, t, blt);
+    if (n_lock > 0) {
+        q.split_phase = 2; q.order = lock_order;
+        hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
+    }
+    return hipGetLastError();
+}
+int viterbi_tube_record_ints() { return kTubeRec; }
+hipError_t viterbi_verify_fetch(long long *dst, bool reset) {
+    hipError_t e = hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_verify_dbg), sizeof(long long) * 16);
+    if (e == hipSuccess && reset) { static long long z[16]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_verify_dbg), z, sizeof(z)); }
+    return e;
+}
+hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order,
+                                const int32_t *lock_order, int n_lock, hipStream_t s) {
+    if (p.n_seg == 0) return hipSuccess;
+    hipError_t e = p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, lock_order, n_lock, s)
+                                      : launch_split_kernels<50>(p, t, host_lt_band, seg_order, lock_order, n_lock, s);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(viterbi_segmap_kernel, dim3((unsigned)p.n_seg), dim3(1024), 0, s, p);
+    hipLaunchKernelGGL(viterbi_stitch_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, p);
+    hipLaunchKernelGGL(viterbi_segtrace_kernel, dim3((unsigned)p.n_seg), dim3(256), 0, s, p);
+    hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, s, p, t);
+    hipLaunchKernelGGL(viterbi_exact_kernel, dim3((unsigned)p.n_clips), dim3(64), 0, s, p, t);
+    return hipGetLastError();
 }
 
 static bool band_geometry(const PassParams &p) {

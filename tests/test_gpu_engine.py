@@ -654,6 +654,63 @@ def test_a_process_holding_a_live_handle_exits_after_an_exception():
         assert "chunks" in r.stdout and "Error" in r.stderr and "end of script" not in r.stdout, (variant, r.stdout, r.stderr[-400:])
 
 
+@pytest.mark.parametrize("sr", [44100, 22050])
+def test_time_split_viterbi_equals_the_sequential_run(sr, monkeypatch):
+    """viterbi.hip "Time-split Viterbi": clips cut into segments that run concurrently (speculative runs from a guessed
+    column, lock-on runs from the previous segment's end column, stitched back-trace, verification of every decision the
+    accumulated rounding bound could flip, sequential redo of what cannot be certified).  AEGIS_TIME_SPLIT=<steps> forces
+    it with short segments; the outputs must be those of the sequential kernel (AEGIS_TIME_SPLIT=0) bit for bit: tonal,
+    polyphonic and noisy clips, a clip with a long silence (no voiced note near its boundaries: lock-on late or never),
+    pure silence (exact ties everywhere), a clip shorter than a segment, an empty one; both band kernels (H = 25, 50)."""
+    clips = [signals.guitar_clip(40.0, sr=sr, seed=5), signals.polyphonic_clip(21.7, sr=sr, seed=7),
+             signals.guitar_clip(15.0, sr=sr, seed=3, noise_dbfs=-12.0),
+             np.concatenate([signals.guitar_clip(6.0, sr=sr, seed=5), np.zeros(int(sr * 14.0), np.float32), signals.guitar_clip(7.0, sr=sr, seed=6)]),
+             np.zeros(int(sr * 9.0), np.float32), signals.guitar_clip(1.2, sr=sr, seed=8), np.zeros(0, np.float32),
+             signals.sine_sweep(12.0, sr=sr)]
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    ref_h = _lib.Handle(sample_rate=sr)
+    ref = ref_h.analyze_batch(clips, stages=_lib.STAGE_PYIN)
+    assert ref_h.param("split_passes") == 0
+    ref_h.close()
+    for seg, warm in (("256", "128"), ("512", "64"), ("1024", "128")):
+        monkeypatch.setenv("AEGIS_TIME_SPLIT", seg)
+        monkeypatch.setenv("AEGIS_SPLIT_WARMUP", warm)
+        h = _lib.Handle(sample_rate=sr)
+        got = h.analyze_batch(clips, stages=_lib.STAGE_PYIN)
+        assert h.param("split_passes") == 1 and h.param("last_split_segments") > len(clips)
+        print(f"sr {sr} segments of {seg} steps, warm-up {warm}: {h.param('last_split_segments')} segments, "
+              f"{h.param('split_flagged_clips')} of {len(clips)} clips redone sequentially")
+        for i in range(len(clips)):
+            for k in ("f0", "voiced_flag", "voiced_prob"):
+                np.testing.assert_array_equal(got[i][k], ref[i][k], err_msg=f"segments {seg}/{warm} clip {i} {k}")
+        one = h.analyze_batch([clips[0]], stages=_lib.STAGE_PYIN)[0]            # a single clip, the other entry's schedule
+        np.testing.assert_array_equal(one["f0"], ref[0]["f0"])
+        dev = _analyze_on_device(h, clips) if sr == 44100 else None
+        if dev is not None:
+            np.testing.assert_array_equal(dev["f0"], np.concatenate([r["f0"] for r in ref]))
+        assert h.param("split_flagged_clips") <= 3 * 3                           # the silent clips at most (every call)
+        h.close()
+    monkeypatch.delenv("AEGIS_TIME_SPLIT")
+    monkeypatch.delenv("AEGIS_SPLIT_WARMUP")
+    # automatic: a pass bound by the recurrence of its longest clip is split (one long clip; a few), a pass of many short
+    # clips is not
+    h = _lib.Handle(sample_rate=sr)
+    long_clip = signals.guitar_clip(100.0, sr=sr, seed=12)
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    seq_h = _lib.Handle(sample_rate=sr)
+    want = seq_h.analyze_batch([long_clip, clips[1]], stages=_lib.STAGE_PYIN)
+    seq_h.close()
+    monkeypatch.delenv("AEGIS_TIME_SPLIT")
+    got = h.analyze_batch([long_clip, clips[1]], stages=_lib.STAGE_PYIN)
+    assert h.param("split_passes") == 1 and h.param("last_split_segments") >= 4
+    for a, b in zip(got, want):
+        for k in ("f0", "voiced_flag", "voiced_prob"):
+            np.testing.assert_array_equal(a[k], b[k], err_msg=f"automatic split {k}")
+    h.analyze_batch([clips[5]] * 40, stages=_lib.STAGE_PYIN)
+    assert h.param("split_passes") == 1 and h.param("last_split_segments") == 0
+    h.close()
+
+
 def test_graft_entry_smoke():
     """The driver's smoke() hook itself: one small analyze on cuda:0 checked against the oracle."""
     import __graft_entry__ as g

@@ -1,0 +1,73 @@
+"""Time-split Viterbi (viterbi.hip) against the sequential kernel on the latency-bound workloads:
+BASELINE.json configs[1] (one 180 s clip), rank 0's shard of the 512-clip folder on 8 GPUs (64 ragged clips: what every
+GPU of the driver's N = 8 run holds), the 64 x 180 s shard.  Prints one JSON line per workload.
+
+    python tools/bench_split.py [single] [rank8] [shard]"""
+import json, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import bench
+from spectrogram_midi_amd import _lib, dist as adist
+from tools import signals
+
+which = sys.argv[1:] or ["single", "rank8", "shard"]
+dev = torch.device("cuda", 0)
+
+
+def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", None)), kinds=None):
+    n = np.array([len(c) for c in clips], np.int64)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    F = int((n // 512 + 1).sum())
+    d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+    outs = {"f0": torch.empty(F, dtype=torch.float64, device=dev), "voiced_flag": torch.empty(F, dtype=torch.uint8, device=dev),
+            "voiced_prob": torch.empty(F, dtype=torch.float64, device=dev), "rms": torch.empty(F, dtype=torch.float32, device=dev),
+            "rake_mask": torch.empty(F, dtype=torch.uint8, device=dev)}
+    ptrs = {k: v.data_ptr() for k, v in outs.items()}
+    res, ref = {}, None
+    for name, env in modes:
+        if env is None:
+            os.environ.pop("AEGIS_TIME_SPLIT", None)
+        else:
+            os.environ["AEGIS_TIME_SPLIT"] = env
+        h = _lib.Handle()
+        h.set_profiling(True)
+        ts = []
+        for _ in range(reps + 1):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            h.analyze_batch_device(d_pcm.data_ptr(), off, ptrs, sync=True)
+            ts.append(time.perf_counter() - t0)
+        ms = float(np.median(ts[1:])) * 1e3
+        got = {k: v.cpu().numpy() for k, v in outs.items()}
+        if ref is None:
+            ref = got
+        same = all(np.array_equal(got[k], ref[k], equal_nan=True) for k in got)
+        res[name] = {"ms": round(ms, 3), "audio_s_per_s": round(float(n.sum()) / 44100 / (ms * 1e-3), 1),
+                     "kernel_ms": {k: round(h.kernel_ms(k), 3) for k in ("frame", "pyin_obs", "viterbi", "finalize")},
+                     "segments": h.param("last_split_segments"), "calls": reps + 1,
+                     "clips_redone_sequentially": h.param("split_flagged_clips"), "of_which_never_locked": h.param("split_unlocked_clips"),
+                     "outputs_equal_sequential": bool(same),
+                     "verify": dict(zip(("frames", "tubes_opened", "tubes_recorded", "too_wide", "-", "closed_elsewhere", "open_at_exact_run", "too_deep", "max_depth", "oob_in_bound", "last_column_tie", "records_full", "tubes_resolved", "path_changed"), (int(x) for x in h.debug_fetch("split_verify")[:14])))}
+        if h.param("last_split_segments") > 0:
+            lk = h.debug_fetch("seg_lock")
+            lk = lk[lk != 0]
+            res[name]["lock_on_steps"] = {"runs": int(len(lk)), "never": int((lk < 0).sum()), "median": float(np.median(lk[lk > 0])) if (lk > 0).any() else None,
+                                          "p90": float(np.quantile(lk[lk > 0], 0.9)) if (lk > 0).any() else None, "max": int(lk.max()) if len(lk) else None,
+                                          "over_256": int((lk > 256).sum())}
+        if h.param("last_split_segments") > 0 and kinds is not None:
+            fl = h.debug_fetch("split_flags")
+            order = np.argsort(-n, kind="stable")                    # the pass takes its clips longest first
+            res[name]["flagged"] = [(kinds[order[i]], round(float(n[order[i]]) / 44100), int(fl[i])) for i in range(len(fl)) if fl[i]]
+        h.close()
+    print(json.dumps({"workload": label, "clips": len(clips), "audio_s": round(float(n.sum()) / 44100, 1), "frames": F, **res}), flush=True)
+
+
+if "single" in which:
+    run([signals.guitar_clip(180.0, seed=1)], "configs[1]: one 180 s clip")
+if "rank8" in which:
+    durations = bench.folder_durations(512)
+    mine = adist.shard_clips(durations, 8)[0]
+    run(bench.make_folder_clips(mine, durations), "rank 0 of 8: its 64 clips of the 512-clip folder", kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
+if "shard" in which:
+    run(bench.make_clips(64, 180.0, seed0=1), "64 x 180 s", modes=(("sequential", "0"), ("forced 4096", "4096")), kinds=["guitar"] * 64)
