@@ -476,7 +476,7 @@ def main():
     events_ms = reduce_max(events_ms)
 
     # ---- sub-records of the same run ("H2D included and reported separately") ----------------
-    host_inclusive = engine_e2e = uniform_shard = None
+    host_inclusive = engine_e2e = uniform_shard = single_clip = None
     if not args.no_extras:
         import io
         from spectrogram_midi_amd.engine import AegisEngine
@@ -519,6 +519,33 @@ def main():
                                        "analyze_value": round(total_audio / dt_an, 2), "value": round(total_audio / dt_all, 2),
                                        "entry": "AegisEngine.analyze_arrays + extract_events(raw, file-like) per clip"}}
         del raws
+        # (2b) BASELINE.json configs[1]: ONE 180 s clip on this GPU (the time-split Viterbi's case: a pass bound by the recurrence
+        # of one clip), device-resident like the main line; the sequential kernel (AEGIS_TIME_SPLIT=0) beside it
+        if args.config == "folder" and world == 1:
+            from tools import signals
+            y1 = signals.guitar_clip(180.0, SR, seed=1)
+            d_y1 = torch.from_numpy(y1).to(dev)
+            o1, p1 = device_outputs(handle.frames_for(len(y1)))
+            off1 = np.array([0, len(y1)], np.int64)
+            single_clip = {"workload": "configs[1]: one 180 s clip, device-resident"}
+            for name, env in (("time_split", None), ("sequential", "0")):
+                if env is None:
+                    os.environ.pop("AEGIS_TIME_SPLIT", None)
+                else:
+                    os.environ["AEGIS_TIME_SPLIT"] = env
+                h1 = _lib.Handle(sample_rate=SR, hop_length=HOP, device=local_rank)
+                ts = []
+                for _ in range(6):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    h1.analyze_batch_device(d_y1.data_ptr(), off1, p1, rake_sensitivity=0.6, stages=_lib.STAGE_ALL, sync=True)
+                    ts.append(time.perf_counter() - t0)
+                ms1 = float(np.median(ts[1:])) * 1e3
+                single_clip[name] = {"ms": round(ms1, 3), "value": round(180.0 / (ms1 * 1e-3), 1), "unit": "audio-seconds/s",
+                                     "segments": h1.param("last_split_segments"), "clips_redone_sequentially": h1.param("split_flagged_clips")}
+                h1.close()
+            os.environ.pop("AEGIS_TIME_SPLIT", None)
+            del d_y1, o1
         # (3) the uniform 64 x 180 s shard earlier rounds quoted, on this GPU alone
         if args.config == "folder" and world == 1:
             sclips = make_clips(64, 180.0, seed0=1)
@@ -622,6 +649,7 @@ def main():
                        "backend": None if world == 1 else ("gloo" if args.rehearse_on_one_gpu else "nccl (RCCL)")},
         }
         line["uniform_shard"], line["host_inclusive"], line["engine_e2e"] = uniform_shard, host_inclusive, engine_e2e
+        line["single_clip"] = single_clip
         if vstats is not None and vstats["wave_steps"] > 0:
             line["viterbi_list_only_rate"] = round(vstats["list_only"] / max(1, vstats["wave_steps"] - vstats["skipped"]), 5)
             # voiced waves whose 64 targets are all dead at an easy frame skip the step (exact: viterbi.hip)

@@ -711,6 +711,35 @@ def test_time_split_viterbi_equals_the_sequential_run(sr, monkeypatch):
     h.close()
 
 
+def test_time_split_on_one_rank_of_the_folder(monkeypatch):
+    """Rank 0's shard of BASELINE.json configs[3] on 8 GPUs (64 ragged clips of 81 .. 328 s: tonal, polyphonic and noisy ones;
+    1.04 M frames) with the time split forced on every clip: 250-odd concurrent segments, ~20 000 tubes resolved by the exact
+    walk, the noisy clips (no voiced note to lock on to, tubes as long as the clip) redone by the sequential kernel -- and
+    every output array equal to the sequential pass's, bit for bit."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from spectrogram_midi_amd import dist as adist
+    durations = bench.folder_durations(512)
+    mine = adist.shard_clips(durations, 8)[0]
+    clips = bench.make_folder_clips(mine, durations)
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    h = _lib.Handle()
+    ref = _analyze_on_device(h, clips)
+    h.close()
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "4096")
+    h = _lib.Handle()
+    got = _analyze_on_device(h, clips)
+    assert h.param("split_passes") == 1 and h.param("last_split_segments") > 200
+    flagged = h.param("split_flagged_clips")
+    v = h.debug_fetch("split_verify")
+    assert 0 < flagged <= 16 and v[12] > 2000 and v[13] > 500            # tubes resolved by the exact walk; the path changed in many
+    h.close()
+    monkeypatch.delenv("AEGIS_TIME_SPLIT")
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
 def test_graft_entry_smoke():
     """The driver's smoke() hook itself: one small analyze on cuda:0 checked against the oracle."""
     import __graft_entry__ as g
