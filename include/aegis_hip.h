@@ -94,6 +94,16 @@ int aegis_abi_version(void);
 /* aegis_engine.py:17-20.  Builds the device tables (Hann window, Slaney mel
  * filterbank, pYIN priors, HMM log-transitions) and the workspace. */
 int aegis_create(const aegis_config *cfg, aegis_handle **out);
+/* Threads.  Every entry that takes a handle holds the handle's mutex for the whole call: a handle may be SHARED by several
+ * threads (the reference's servers share one engine across requests, server.py:51) and their calls are serialised; use one
+ * handle per thread for concurrency.  What is NOT supported is driving one call from two threads -- a helper thread issuing
+ * HIP work into a handle's streams while another thread is inside a call on it (round 3's feeder-thread experiment hung
+ * inside the runtime) -- and aegis_destroy racing with a call in flight.  One handle sizes its workspace from the device
+ * memory that was free when it was created (max_frames_per_pass = 0): several handles on one device should be given an
+ * explicit max_frames_per_pass.
+ * aegis_destroy waits for the handle's own streams (at most ten seconds; work still running then is leaked with a message
+ * on stderr rather than waited for), synchronises the device and frees everything; with aegis_stream objects still open it
+ * only marks the handle and the last aegis_stream_free() tears it down. */
 void aegis_destroy(aegis_handle *h);
 const char *aegis_last_error(const aegis_handle *h); /* h may be NULL: last create error */
 
@@ -307,7 +317,9 @@ int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64
 
 /* Scalar parameters derived at create time.  name in {"min_period","max_period",
  * "n_lags","n_pitch_bins","transition_width","n_trans_classes","max_frames_per_pass",
- * "lag_stride","yin_stride","obs_stride","last_frames","pyin_init"}. */
+ * "lag_stride","yin_stride","obs_stride","last_frames","pyin_init"}; of the last call (its last pass): "last_passes",
+ * "last_chunks", "last_dense", "last_proportional", "last_balanced", "last_persistent", "last_split_segments"; since create:
+ * "split_passes", "split_segments", "split_flagged_clips", "split_unlocked_clips" (time-split Viterbi, csrc/viterbi.hip). */
 int64_t aegis_get_param(const aegis_handle *h, const char *name);
 
 /* Copies an intermediate of the most recent pass (device -> host), for stage-level

@@ -522,6 +522,15 @@ int aegis_analyze_batch_device(aegis_handle *h, const float *d_pcm, const int64_
     if (!h->persistent && h->persistent_wanted && h->persist_cooldown > 0 && --h->persist_cooldown == 0)
         h->persistent = true;                 // the give-up is not for good: whatever serialised the kernels may be gone
     int rc = analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+    // The default pass size was taken from the device memory free when the handle was created; other handles, the caller's
+    // own buffers or a second workspace may have taken it since: on an allocation failure the passes are halved (down to
+    // 2^21 frames) and the call planned again.
+    while (rc == AEGIS_ERR_NOMEM && h->max_frames_per_pass > ((int64_t)1 << 21)) {
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        h->max_frames_per_pass = std::max<int64_t>((int64_t)1 << 21, h->max_frames_per_pass / 2);
+        rc = analyze_device_locked(h, d_pcm, sample_offsets, n_clips, rake_sensitivity, stages, dout, stream_v, sync);
+    }
     if (rc != AEGIS_OK && h->persist_gave_up) {
         // The single Viterbi launch of a balanced pass found the frame stage not running beside it (a profiler collecting
         // counters serialises kernels, for one): this handle goes back to one launch per chunk for the next 16 calls and
@@ -1199,6 +1208,13 @@ int aegis_analyze_batch(aegis_handle *h, const float *const *pcm, const int64_t 
         HostFeed feed{pcm, static_cast<float *>(h->io_pcm.p), std::vector<int64_t>((size_t)n_clips, 0)};
         rc = analyze_device_locked(h, static_cast<const float *>(h->io_pcm.p), off.data(), n_clips,
                                    rake_sensitivity, stages, &d, nullptr, 2, &feed);
+        if (rc == AEGIS_ERR_NOMEM && h->max_frames_per_pass > ((int64_t)1 << 21)) {      // as in aegis_analyze_batch_device
+            (void)hipDeviceSynchronize();
+            (void)hipGetLastError();
+            h->max_frames_per_pass = std::max<int64_t>((int64_t)1 << 21, h->max_frames_per_pass / 2);
+            --attempt;
+            continue;
+        }
         if (rc != AEGIS_OK) return rc;
         if (!h->persist_pending) break;
         HIPCHK(h, hipStreamSynchronize(s));
@@ -1264,7 +1280,10 @@ static int cqt_bank_locked(aegis_handle *h, int32_t &n_bins, int32_t &bins_per_o
         if (b.dev) { (void)hipFree(b.dev); b.dev = nullptr; }
         const char *msg = build_cqt_bank(b, h->tab.sr, n_bins, fmin, bins_per_octave, filter_scale);
         if (msg[0]) { h->err = msg; b.n_bins = 0; return AEGIS_ERR_INVALID; }
-        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&b.dev), b.data.size() * 4));
+        // + 64 KiB: the slide kernel refills a tile's register queue unconditionally, so a wave's last groups request up to
+        // kSlotDepth KiB past its stream (never used)
+        HIPCHK(h, hipMalloc(reinterpret_cast<void **>(&b.dev), b.data.size() * 4 + 65536));
+        HIPCHK(h, hipMemset(reinterpret_cast<char *>(b.dev) + b.data.size() * 4, 0, 65536));
         HIPCHK(h, hipMemcpy(b.dev, b.data.data(), b.data.size() * 4, hipMemcpyHostToDevice));
     }
     return AEGIS_OK;

@@ -396,6 +396,7 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
             fresh_next[k] = (q2 + 4 < npass && sn >= 0 && sn < n) ? y[sn] : 0.0f;
         }
         const int na = na_next;
+        __builtin_assume(na >= 1);                       // tile 0 spans every pass: its block is not behind a branch
         na_next = q2 + 2 < npass ? active_tiles(q2 + 2) : 0;
         const int ncont = na_next < na ? na_next : na;   // tiles whose queue keeps running into the next pair
         {                                                // tiles that join in the next pair: start their queues now
@@ -455,7 +456,15 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
                                     acc[T][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(slot[T][si][e], b[ct][e], acc[T][ct], 0, 0, 0);
                             // the slot just consumed takes the group LA further down the stream: inside this pair of passes, or in
                             // the next pair if the tile is still active there
+#ifdef CQT_COND_REFILL
                             if (hp * kGroups + g + LA < 2 * kGroups || T < ncont) slot[T][si] = frag(T, q * kGroups + g + LA);
+#else
+                            // unconditional (a tile in its last pair requests up to LA KiB past its stream -- the next wave's or
+                            // tile's fragments, or the padding behind the bank -- and never uses them): every group of an active
+                            // tile then issues exactly one load, so the compiler's s_waitcnt vmcnt counts stay at the queue depth
+                            // instead of falling to 0 by the last group of a pair
+                            slot[T][si] = frag(T, q * kGroups + g + LA);
+#endif
                             self(self, std::integral_constant<int, T + 1>{});
                         }
                     }

@@ -69,5 +69,17 @@ if "rank8" in which:
     durations = bench.folder_durations(512)
     mine = adist.shard_clips(durations, 8)[0]
     run(bench.make_folder_clips(mine, durations), "rank 0 of 8: its 64 clips of the 512-clip folder", kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
+if "rank8tonal" in which:       # rank 0's shard with the noisy eighth of the folder replaced by tonal clips: what the split does when every clip locks on
+    durations = bench.folder_durations(512)
+    mine = adist.shard_clips(durations, 8)[0]
+    kinds_save = bench.FOLDER_KINDS
+    bench.FOLDER_KINDS = ("guitar",) * 6 + ("polyphonic", "guitar")
+    run(bench.make_folder_clips(mine, durations), "rank 0 of 8, noisy clips replaced by tonal ones", reps=8, kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
+    bench.FOLDER_KINDS = kinds_save
+if "ranks" in which:            # every rank's shard of the folder at N = 8, one after the other on this GPU: what the driver's N = 8 run would see
+    durations = bench.folder_durations(512)
+    shards = adist.shard_clips(durations, 8)
+    for r in range(8):
+        run(bench.make_folder_clips(shards[r], durations), f"rank {r} of 8", reps=8, kinds=[bench.FOLDER_KINDS[i % 8] for i in shards[r]])
 if "shard" in which:
     run(bench.make_clips(64, 180.0, seed0=1), "64 x 180 s", modes=(("sequential", "0"), ("forced 4096", "4096")), kinds=["guitar"] * 64)
