@@ -111,6 +111,7 @@ struct aegis_handle {
     std::vector<SplitCheck> split_checks;     // split passes of the call in flight: their clip flags are read after the synchronisation
     int64_t split_stats[4] = {0, 0, 0, 0};    // since create: split passes, segments, clips flagged for the sequential kernel, lock-on runs that never locked
     int last_split_segments = 0;
+    int64_t last_carried_steps = 0;          // longest carry-on run (viterbi_band.inc, phase 3) of the call's last split pass
     std::vector<int64_t> last_split_flags;   // per clip of the call's last split pass (pass order: longest first): the verification's verdict bits
     int last_passes = 0, last_chunks = 0, last_dense = 0, last_proportional = 0, last_balanced = 0, last_persistent = 0;   // of the last call (its last pass)
     // profiling
@@ -590,6 +591,12 @@ static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
         h->last_split_flags.assign(flags.begin(), flags.end());
         for (int i = 0; i < sc.nc; ++i)
             if (flags[i]) { redo.push_back(i); if (flags[i] & 1u) ++h->split_stats[3]; }
+        uint32_t counts[2] = {0, 0};
+        HIPCHK(h, hipMemcpy(counts, sc.p.tube_count, 8, hipMemcpyDeviceToHost));
+        h->last_carried_steps = counts[1];
+        // a carry-on run is the sequential recurrence behind the split pass: when the longest one took more than a quarter of
+        // what the pass would have taken sequentially, the next 32 calls of this handle plan their passes sequentially
+        if (sc.automatic && (double)counts[1] * (t.half_width == 25 ? 3.1e-6 : 7.3e-6) > 0.25 * sc.t_seq) h->split_cooldown = 32;
         if (redo.empty()) continue;
         h->split_stats[2] += (int64_t)redo.size();
         if (sc.automatic) {
@@ -767,7 +774,15 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 // work if that is more (they overlap); split pass: the frame stage first (3/4 of the work, not overlapped),
                 // then one segment + warm-up + a typical lock-on tail, stitch and verification.
                 const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, work = (double)fp * 43e-9;
-                const int64_t sl = std::max<int64_t>(768, ((fp - nc) / std::max(1, h->n_cus) + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                int64_t sl = std::max<int64_t>(768, ((fp - nc) / std::max(1, h->n_cus) + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                // one workgroup per segment, one per compute unit: a 257th segment would run alone after the other 256
+                // (rank 0 of the folder on 8 GPUs: 258 segments, speculative runs 24.0 ms instead of 13)
+                for (int guard = 0; guard < 64; ++guard) {
+                    int64_t ns = 0;
+                    for (int i = 0; i < nc; ++i) ns += std::max<int64_t>(1, (frames[pc[i]] - 1 + sl / 2) / sl);
+                    if (ns <= h->n_cus) break;
+                    sl = (sl + sl / 32 + kViterbiChunk) / kViterbiChunk * kViterbiChunk;
+                }
                 const double t_seq = std::max((double)maxF * step, work);
                 const double t_split = 0.75 * work + (double)(sl + h->split_warmup + 600) * step + 2.5e-3;
                 if (t_split < 0.8 * t_seq) { seglen = sl; split_auto = true; }
@@ -943,11 +958,11 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             if (proportional) ENS(clip_tb, (size_t)(nk + 1) * nc * 8);
             if (tsplit) {
                 ENS(seg64, m.seg64.size() * 8); ENS(seg32, m.seg32.size() * 4);
-                ENS(seg_col, (size_t)n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, (size_t)n_seg * 3 * 4);
+                ENS(seg_col, (size_t)2 * n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, (size_t)n_seg * 3 * 4);
                 ENS(colhist, (size_t)fp * S * 8); ENS(colG, (size_t)fp * 8); ENS(colkg, (size_t)fp * 4); ENS(clip_flag, (size_t)nc * 4);
                 ENS(flag_order, (size_t)nc * 4);
                 tube_cap = (int)std::max<int64_t>(4096, fp / 128);
-                ENS(tube_buf, (size_t)tube_cap * viterbi_tube_record_ints() * 4); ENS(tube_at, (size_t)fp * 4); ENS(tube_count, 4);
+                ENS(tube_buf, (size_t)tube_cap * viterbi_tube_record_ints() * 4); ENS(tube_at, (size_t)fp * 4); ENS(tube_count, 8);
             }
         }
         if (stages & AEGIS_STAGE_MEL) { ENS(melpow, fp * t.n_mels * 4); ENS(clipmax, nc * 4); ENS(rake_raw, fp); }
@@ -967,7 +982,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             HIPCHK(h, hipMemsetAsync(w.seg_i32.p, 0, (size_t)n_seg * 3 * 4, fa));       // seg_lock = 0 for the segments without a lock-on run
             HIPCHK(h, hipMemsetAsync(w.clip_flag.p, 0, (size_t)nc * 4, fa));
             HIPCHK(h, hipMemsetAsync(w.tube_at.p, 0, (size_t)fp * 4, fa));
-            HIPCHK(h, hipMemsetAsync(w.tube_count.p, 0, 4, fa));
+            HIPCHK(h, hipMemsetAsync(w.tube_count.p, 0, 8, fa));       // tubes recorded, longest carry-on run (steps)
         }
         PassParams p = base_params(t);
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
@@ -1033,7 +1048,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             p.seg_T = g32; p.seg_store = g32 + n_seg; p.seg_prev = g32 + 2 * n_seg; p.seg_clip = g32 + 3 * n_seg;
             p.clip_seg0 = g32 + 4 * n_seg;
             d_seg_order = g32 + 4 * n_seg + nc + 1; d_lock_order = d_seg_order + n_seg;
-            p.seg_col = static_cast<double *>(w.seg_col.p);
+            p.seg_col = static_cast<double *>(w.seg_col.p); p.seg_col2 = p.seg_col + (size_t)n_seg * S;
             p.seg_map = static_cast<uint16_t *>(w.seg_map.p);
             p.seg_kg = static_cast<int32_t *>(w.seg_i32.p); p.seg_lock = p.seg_kg + n_seg; p.seg_end = p.seg_kg + 2 * n_seg;
             p.colhist = static_cast<double *>(w.colhist.p); p.colG = static_cast<double *>(w.colG.p); p.colkg = static_cast<int32_t *>(w.colkg.p);
@@ -2001,6 +2016,7 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "split_segments") return h->split_stats[1];
     if (n == "split_flagged_clips") return h->split_stats[2];
     if (n == "split_unlocked_clips") return h->split_stats[3];
+    if (n == "split_carried_steps") return h->last_carried_steps;
     if (n == "last_chunks") return h->last_chunks;
     if (n == "last_dense") return h->last_dense;
     if (n == "last_proportional") return h->last_proportional;

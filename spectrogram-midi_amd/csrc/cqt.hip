@@ -259,11 +259,13 @@ __device__ __forceinline__ int ring_idx(int u) {
 // Groups (of 4 k-steps) that tile T's A fragments are fetched ahead of their MFMAs.  Tile T is only ever active
 // together with tiles 0..T-1, so a group lasts >= (T+1) x 12 MFMAs = (T+1) x 384 cycles: the longest filters run
 // alone in the outer passes and need the deepest queue.  Must divide the 4 groups of a pass.
-// Round 4: queues of 8 / 8 / 4 groups (tile 0, tiles 1..3, the others) instead of 4 / 2 / 1: 4.27 -> 4.10 ms for 64 x 30 s.
-// Depth is not what bounds the outer passes, though: the compiler places the waits for these loads, vector loads return
-// in order, and the number of refills issued between a request and its use is a run-time figure (the tile chain
-// branches), so every group opens with s_waitcnt vmcnt(<= 3) and, from the fourth group of a pair on, vmcnt(0) -- whatever
-// the depth, a group never has more than a handful of fragments in flight behind it.
+// Round 4: queues of 8 / 8 / 4 groups (tile 0, tiles 1..3, the others) instead of 4 / 2 / 1, and refills that are
+// UNCONDITIONAL.  The compiler places the waits for these loads; vector loads return in order, so the wait before a
+// group's MFMAs is vmcnt(number of loads certainly issued since the fragment it needs).  While a refill sat behind
+// `if (tile continues into the next pair)`, no refill counted as certain: the count fell by one per group and the last
+// group of every pair waited with vmcnt(0) -- for the refill issued 400 cycles earlier, a full memory latency, once per
+// pair of passes.  With unconditional refills (and tile 0 known active) every group waits vmcnt(depth - 1):
+// 4.05 -> 3.5 ms for 64 x 30 s, and the depth no longer matters between 4 and 8.
 #ifndef CQT_LA0
 #define CQT_LA0 8
 #endif
@@ -398,7 +400,9 @@ __global__ __launch_bounds__(256) void cqt_slide_kernel(CqtArgs a, CqtMeta m, co
         const int na = na_next;
         __builtin_assume(na >= 1);                       // tile 0 spans every pass: its block is not behind a branch
         na_next = q2 + 2 < npass ? active_tiles(q2 + 2) : 0;
+#ifdef CQT_COND_REFILL
         const int ncont = na_next < na ? na_next : na;   // tiles whose queue keeps running into the next pair
+#endif
         {                                                // tiles that join in the next pair: start their queues now
             auto fill = [&](auto self, auto tc) -> void {
                 constexpr int T = decltype(tc)::value;

@@ -389,7 +389,7 @@ __global__ __launch_bounds__(64) void viterbi_stitch_kernel(PassParams p) {
     if (c >= p.n_clips) return;
     const int S = 2 * p.n_bins, a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
     bool bad = false;
-    for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] < 0;
+    for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] == -1;      // (-2: a carry-on run replaced it by the sequential run)
     int e = p.seg_kg[b - 1];
     for (int k = b - 1; k >= a; --k) { p.seg_end[k] = e; e = p.seg_map[(int64_t)k * S + e]; }
     p.states[p.frame_off[c]] = e;
@@ -438,9 +438,21 @@ __global__ __launch_bounds__(256) void viterbi_segtrace_kernel(PassParams p) {
 // g_verify_dbg: [0] -, [1] tubes opened, [2] tubes recorded, then the reasons a clip was flagged: [3] tube wider
 // than kTubeCap, [5] tube closed on another state than the decoded one, [6] tube open at the exact run, [7] deeper than
 // kTubeDepth, [8] largest depth recorded, [9] out-of-band candidate within the bound, [10] last column's maximum not unique
-// within the bound, [11] record buffer full, [12] tubes resolved by the exact walk, [13] of which changed the path
+// within the bound, [11] record buffer full, [12] tubes resolved by the exact walk, [13] of which changed the path,
+// [14] tubes with a rail, [15] frames those rails span
+//
+// RAILS.  A tube does not always collapse: two unvoiced states whose best predecessor is the state itself, frame after frame,
+// and whose values tie run side by side for as long as the stretch is unvoiced -- the two EDGE bins of a clip (or tail) that is
+// unvoiced throughout are the standing case (the truncated transition window gives both the same, highest, stay probability),
+// and a recording that ends in silence is one.  Walking such a tube level by level is a sequential chain as long as the
+// Viterbi's own.  So when every member of a level is unvoiced and its only near-best predecessor is itself, the wave checks
+// the next frames in PARALLEL (one lane per frame: is `self` alone within the bound for every member?), and the record holds
+// the stretch as one entry: the level it hangs under and its length.  The exact walk runs the members' chains side by side
+// through it (one lane each: the same two additions per frame as the decoded path's own chain).
 constexpr int kTubeCap = 16, kTubeDepth = 48;
-constexpr int kTubeRec = 4 + (kTubeDepth + 1) * (1 + kTubeCap);      // ints of a record: clip, top frame, depth, -, then per depth n + states
+// ints of a record: clip, top frame, levels, slot, then per level n + states, then the rail: the level it hangs under (-1: none) and its length
+constexpr int kTubeRec = 4 + (kTubeDepth + 1) * (1 + kTubeCap) + 2;
+constexpr int kRailAt = kTubeRec - 2, kRailLen = kTubeRec - 1;
 __device__ unsigned long long g_verify_dbg[16];
 
 // twice the distance the hybrid run's values can be from the sequential run's at workspace frame fr of a clip that starts
@@ -547,13 +559,58 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
             if (cnt > 1) return;
         }
     }
-    int depth = 0;
+    // decisions into frames ftop, ftop - 1, ... (down to the first boundary) at which `self` is the only predecessor within the
+    // bound for every one of the n unvoiced states mem[]: how many in a row.  One lane per frame.
+    auto rail_scan = [&](const int *mem, int nm, int64_t ftop) -> int {
+        int L = 0;
+        const int64_t maxL = ftop - fx;
+        while (L < maxL) {
+            const int64_t fk = ftop - L - lane;
+            bool ok = fk > fx;
+            if (ok) {
+                const double thr = split_bound(p, fk, fc, nsp);
+                const double *__restrict__ col = p.colhist + (fk - 1) * (int64_t)S;
+                const double G = p.colG[fk - 1];
+                const int kg = p.colkg[fk - 1], bg = kg >= B ? kg - B : kg;
+                for (int q = 0; q < nm && ok; ++q) {
+                    const int b2 = mem[q] - B;
+                    // (a lane reads two runs of <= 2H + 1 consecutive doubles of its frame's column; no branch in the loop, so
+                    // the loads of several candidates are in flight together)
+                    const int blo = b2 - H > 0 ? b2 - H : 0, bhi = b2 + H < B - 1 ? b2 + H : B - 1;
+                    const int clj = b2 < H ? b2 : (b2 > B - 1 - H ? b2 - (B - 1 - 2 * H) : H);
+                    const double self = col[B + b2] + tb.lt_band[((size_t)3 * NC + clj) * W + H];
+                    double other = -INFINITY;
+                    for (int v = 0; v < 2; ++v) {
+                        const double *__restrict__ cv = col + v * B;
+                        const double *__restrict__ ltv = tb.lt_band + (size_t)(v * 2 + 1) * NC * W;
+#pragma unroll 8
+                        for (int bs = blo; bs <= bhi; ++bs) {
+                            const int cl = bs < H ? bs : (bs > B - 1 - H ? bs - (B - 1 - 2 * H) : H);
+                            const double x = cv[bs] + ltv[cl * W + (H + b2 - bs)];
+                            other = fmax(other, (v == 1 && bs == b2) ? -INFINITY : x);
+                        }
+                    }
+                    ok = other < self - thr && !((bg > b2 ? bg - b2 : b2 - bg) > H && G + p.log_tiny >= self - thr);
+                }
+            }
+            const unsigned long long bad = __ballot(!ok);
+            if (bad) { L += (int)__ffsll((long long)bad) - 1; break; }
+            L += 64;
+        }
+        return (int)(L < maxL ? L : maxL);
+    };
+    int depth = 0, rail_at = -1, rail_len = 0;
     int *rec = nullptr;
     int64_t fr = f;
     while (!why) {
         int m = 0;
         const double thr = split_bound(p, fr, fc, nsp);
-        for (int q = 0; q < n && !why; ++q) near_preds(cur[q], fr, thr, nxt, m);
+        bool rail = n > 1 && rail_at < 0;       // every member unvoiced, and its only near-best predecessor is itself
+        for (int q = 0; q < n && !why; ++q) {
+            const int m0 = m;
+            near_preds(cur[q], fr, thr, nxt, m);
+            rail = rail && cur[q] >= B && m == m0 + 1 && nxt[m0] == cur[q];
+        }
         if (why) break;
         if (depth == 0) {
             if (m == 1 && n == 1) { if (nxt[0] != p.states[fr - 1]) why = 5; break; }        // an unambiguous decision: the common case
@@ -563,7 +620,7 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
             slot = (unsigned)__builtin_amdgcn_readfirstlane((int)slot);
             if (slot >= (unsigned)p.tube_cap) { why = 11; break; }
             rec = p.tube_buf + (size_t)slot * kTubeRec;
-            if (lane == 0) { rec[0] = c; rec[1] = (int)(f - fc); rec[3] = (int)slot; rec[4] = n; for (int q = 0; q < n; ++q) rec[5 + q] = cur[q]; }
+            if (lane == 0) { rec[0] = c; rec[1] = (int)(f - fc); rec[3] = (int)slot; rec[4] = n; for (int q = 0; q < n; ++q) rec[5 + q] = cur[q]; rec[kRailAt] = -1; rec[kRailLen] = 0; }
         }
         ++depth; --fr;
         if (depth > kTubeDepth) { why = 7; break; }
@@ -575,6 +632,14 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
             break;
         }
         if (fr <= fx) break;                  // reached the first boundary with the tube still open: the exact column there holds every state's value
+        if (rail) {                           // the level just recorded repeats itself: how far?  (cur == the same states, in the same order)
+            const int L = rail_scan(cur, n, fr);
+            if (L > 0) {
+                rail_at = depth; rail_len = L; fr -= L;
+                if (lane == 0) { rec[kRailAt] = rail_at; rec[kRailLen] = rail_len; }
+                if (fr <= fx) break;
+            }
+        }
     }
     if (lane == 0 && (depth > 0 || why)) {   // (no per-frame counter: one address for a million waves is ~10 ns each)
         if (depth > 0) atomicAdd(&g_verify_dbg[1], 1ull);
@@ -583,9 +648,11 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
             __threadfence();
             // the tube's bottom frame: where the exact walk meets it.  Tubes nest (a decision inside an open tube may be ambiguous
             // itself; its own tube is a subset of the outer one and ends at the same frame or above): the deepest one stays
-            atomicMax(&p.tube_at[fr], (depth << 24) | (rec[3] + 1));
+            const int span = depth + rail_len;
+            atomicMax(&p.tube_at[fr], ((span < 127 ? span : 127) << 24) | (rec[3] + 1));
             atomicAdd(&g_verify_dbg[2], 1ull);
             atomicMax(&g_verify_dbg[8], (unsigned long long)depth);
+            if (rail_len > 0) { atomicAdd(&g_verify_dbg[14], 1ull); atomicAdd(&g_verify_dbg[15], (unsigned long long)rail_len); }
         }
         if (why) { atomicAdd(&g_verify_dbg[why], 1ull); atomicOr(&p.clip_flag[c], 2u); }
     }
@@ -595,6 +662,7 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
     constexpr int CAP = kTubeCap;
     __shared__ double xv[2][CAP];
     __shared__ int ptrx[kTubeDepth + 1][CAP];
+    __shared__ int rec_lds[kTubeRec];
     const int c = blockIdx.x, lane = threadIdx.x;
     const int B = p.n_bins, S = 2 * B, H = p.half_width;
     const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
@@ -633,8 +701,16 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
         if (!mm) continue;
         // ---- a tube whose bottom is frame t: the recurrence over its states, bottom to top ----------------------------
         const int slot = (__builtin_amdgcn_readlane(mark, k0) & 0xffffff) - 1;
-        const int *__restrict__ rec = p.tube_buf + (size_t)slot * kTubeRec;
-        const int D = rec[2];
+        // the record goes to LDS in one batch of loads: walking its levels in global memory cost three dependent loads per level
+        // (a clip with a few hundred tubes: 8 ms of the pass)
+        {
+            const int *__restrict__ grec = p.tube_buf + (size_t)slot * kTubeRec;
+            __syncthreads();
+            for (int i = lane; i < kTubeRec; i += 64) rec_lds[i] = grec[i];
+            __syncthreads();
+        }
+        const int *rec = rec_lds;
+        const int D = rec[2], RA = rec[kRailAt], RL = RA >= 0 ? rec[kRailLen] : 0;
         const int64_t ttop = fc + rec[1];
         {
             const int *bs = rec + 4 + D * (1 + CAP);                   // the bottom set: one state, or several at the first boundary
@@ -642,8 +718,38 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
         }
         __syncthreads();
         int pb = 0;
+        // the rail under level RA: its states (all unvoiced) stay put for RL frames above frame f_lo, every lane its own chain
+        auto rail_steps = [&](int64_t f_lo) {
+            const int *rs = rec + 4 + RA * (1 + CAP);
+            const bool mine = lane < rs[0];
+            double x = mine ? xv[pb][lane] : 0.0;
+            const double ls = mine ? split_lt(p, tb, rs[1 + lane], rs[1 + lane]) : 0.0;
+            const int64_t f_hi = f_lo + RL;
+            double nxt_ou = f_lo + 1 + lane <= f_hi ? p.logunv[f_lo + 1 + lane] : 0.0;
+            for (int64_t f1 = f_lo + 1; f1 <= f_hi; f1 += 64) {
+                const int nb = (int)min((int64_t)64, f_hi - f1 + 1);
+                const double ou = nxt_ou;
+                nxt_ou = f1 + 64 + lane <= f_hi ? p.logunv[f1 + 64 + lane] : 0.0;          // the next block's, under this block's chain
+                if (nb == 64) {
+#pragma unroll
+                    for (int k = 0; k < 64; ++k) {
+                        const double ok = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ou), k), __builtin_amdgcn_readlane(__double2loint(ou), k));
+                        x = ok + (x + ls);
+                    }
+                } else {
+                    for (int k = 0; k < nb; ++k) {
+                        const double ok = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(ou), k), __builtin_amdgcn_readlane(__double2loint(ou), k));
+                        x = ok + (x + ls);
+                    }
+                }
+            }
+            __syncthreads();
+            if (mine) xv[pb][lane] = x;
+            __syncthreads();
+        };
+        if (RA == D) rail_steps(ttop - D - RL);
         for (int d = D - 1; d >= 0; --d) {
-            const int64_t fr = ttop - d;
+            const int64_t fr = ttop - d - (RA >= 0 && d >= RA ? RL : 0);      // (level RA: the lowest frame of its rail)
             const int *cs = rec + 4 + d * (1 + CAP), *ps = rec + 4 + (d + 1) * (1 + CAP);
             const int nc = cs[0], np = ps[0];
             if (lane < nc) {
@@ -661,6 +767,7 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
             }
             __syncthreads();
             pb ^= 1;
+            if (d == RA) rail_steps(fr);
         }
         // the top: one state, or (last frame of the clip) the exact arg-max of the candidates, lowest state first
         int top = 0;
@@ -674,17 +781,21 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
         if (lane == 0) {
             bool changed = states[ttop] != rec[5 + top];
             states[ttop] = rec[5 + top];
-            int idx = ptrx[0][top];
+            int idx = D > 0 ? ptrx[0][top] : top;
             for (int d = 1; d <= D; ++d) {
                 const int st = rec[4 + d * (1 + CAP) + 1 + idx];
-                changed |= states[ttop - d] != st;
+                const int64_t fhi = ttop - d - (RA >= 0 && d > RA ? RL : 0);    // the level's frame (level RA: the top of its rail)
+                changed |= states[fhi] != st;
+                if (d == RA && states[fhi] != st)                               // the rail's frames under it (its lowest one is the next level's business at the bottom of the tube)
+                    for (int64_t tt = fhi - 1; tt >= fhi - RL + (d == D ? 1 : 0); --tt) states[tt] = st;
                 if (d == D) {
                     // (a change here can only happen at the first boundary, where the bottom set holds several states: the path
                     // enters the exact run in another state -- follow the exact run's own pointers down until the old path is met)
                     int sx = st;
-                    int64_t tt = ttop - D;
+                    int64_t tt = ttop - D - RL;
+                    if (d == RA) states[fhi] = st;
                     while (states[tt] != sx) { states[tt] = sx; if (tt == fc) break; sx = p.ptr[tt * (int64_t)S + sx]; --tt; }
-                } else states[ttop - d] = st;
+                } else states[fhi] = st;
                 if (d < D) idx = ptrx[d][idx];
             }
             n_res += 1; n_chg += changed ? 1 : 0;
@@ -791,6 +902,8 @@ static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, 
     hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)p.n_seg), dim3(2 * BP), lds, s, q, t, blt);
     if (n_lock > 0) {
         q.split_phase = 2; q.order = lock_order;
+        hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
+        q.split_phase = 3;                // carry-on runs: a workgroup returns at once unless its lock-on run never met the speculative one
         hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
     }
     return hipGetLastError();

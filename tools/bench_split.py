@@ -48,11 +48,11 @@ def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", None)),
                      "segments": h.param("last_split_segments"), "calls": reps + 1,
                      "clips_redone_sequentially": h.param("split_flagged_clips"), "of_which_never_locked": h.param("split_unlocked_clips"),
                      "outputs_equal_sequential": bool(same),
-                     "verify": dict(zip(("frames", "tubes_opened", "tubes_recorded", "too_wide", "-", "closed_elsewhere", "open_at_exact_run", "too_deep", "max_depth", "oob_in_bound", "last_column_tie", "records_full", "tubes_resolved", "path_changed"), (int(x) for x in h.debug_fetch("split_verify")[:14])))}
+                     "verify": dict(zip(("frames", "tubes_opened", "tubes_recorded", "too_wide", "-", "closed_elsewhere", "open_at_exact_run", "too_deep", "max_depth", "oob_in_bound", "last_column_tie", "records_full", "tubes_resolved", "path_changed", "tubes_with_rail", "rail_frames"), (int(x) for x in h.debug_fetch("split_verify")[:16])))}
         if h.param("last_split_segments") > 0:
             lk = h.debug_fetch("seg_lock")
             lk = lk[lk != 0]
-            res[name]["lock_on_steps"] = {"runs": int(len(lk)), "never": int((lk < 0).sum()), "median": float(np.median(lk[lk > 0])) if (lk > 0).any() else None,
+            res[name]["lock_on_steps"] = {"runs": int(len(lk)), "never": int((lk == -1).sum()), "carried_on": int((lk == -2).sum()), "median": float(np.median(lk[lk > 0])) if (lk > 0).any() else None,
                                           "p90": float(np.quantile(lk[lk > 0], 0.9)) if (lk > 0).any() else None, "max": int(lk.max()) if len(lk) else None,
                                           "over_256": int((lk > 256).sum())}
         if h.param("last_split_segments") > 0 and kinds is not None:
