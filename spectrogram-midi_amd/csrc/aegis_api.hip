@@ -106,11 +106,13 @@ struct aegis_handle {
     // is bound by the recurrence of its longest clip
     int64_t split_seglen = -1;                // -1: automatic
     int split_warmup = 128;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary
-    struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; };
+    struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; double t_front; };
+    hipEvent_t split_ev[2] = {nullptr, nullptr};   // around an automatic split pass's Viterbi kernels: the planning rule checks its estimate against them
     int split_cooldown = 0;                   // automatic mode: calls left without time-split passes after one that did not pay (clips redone sequentially)
     std::vector<SplitCheck> split_checks;     // split passes of the call in flight: their clip flags are read after the synchronisation
     int64_t split_stats[4] = {0, 0, 0, 0};    // since create: split passes, segments, clips flagged for the sequential kernel, lock-on runs that never locked
     int last_split_segments = 0;
+    double last_split_viterbi_ms = 0.0;      // measured Viterbi time of the call's last automatic split pass
     int64_t last_carried_steps = 0;          // longest carry-on run (viterbi_band.inc, phase 3) of the call's last split pass
     std::vector<int64_t> last_split_flags;   // per clip of the call's last split pass (pass order: longest first): the verification's verdict bits
     int last_passes = 0, last_chunks = 0, last_dense = 0, last_proportional = 0, last_balanced = 0, last_persistent = 0;   // of the last call (its last pass)
@@ -447,6 +449,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (auto &ev : h->events) { (void)hipEventDestroy(ev.second.first); (void)hipEventDestroy(ev.second.second); }
     h->events.clear();
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->split_ev) if (e) (void)hipEventDestroy(e);
     T("free tables");
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
@@ -594,9 +597,18 @@ static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
         uint32_t counts[2] = {0, 0};
         HIPCHK(h, hipMemcpy(counts, sc.p.tube_count, 8, hipMemcpyDeviceToHost));
         h->last_carried_steps = counts[1];
-        // a carry-on run is the sequential recurrence behind the split pass: when the longest one took more than a quarter of
-        // what the pass would have taken sequentially, the next 32 calls of this handle plan their passes sequentially
-        if (sc.automatic && (double)counts[1] * (t.half_width == 25 ? 3.1e-6 : 7.3e-6) > 0.25 * sc.t_seq) h->split_cooldown = 32;
+        // The planning rule's estimate against the clock.  A split pass's Viterbi kernels come behind its frame stage, and their
+        // time depends on the material: a lock-on run that never meets the speculative one runs its whole segment and a carry-on
+        // run (the sequential recurrence, viterbi_band.inc phase 3) behind it; with a segment on every compute unit a step takes
+        // 5.5 us instead of 3.1.  When frame stage + measured Viterbi time is not clearly below what the pass would have taken
+        // sequentially, the next 32 calls of this handle plan their passes sequentially.
+        if (sc.automatic && h->split_ev[1]) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->split_ev[0], h->split_ev[1]) == hipSuccess) {
+                h->last_split_viterbi_ms = ms;
+                if (sc.t_front + 1e-3 * ms > 0.92 * sc.t_seq) h->split_cooldown = 32;
+            }
+        }
         if (redo.empty()) continue;
         h->split_stats[2] += (int64_t)redo.size();
         if (sc.automatic) {
@@ -1124,12 +1136,18 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0 + k], 0));
                 }
                 begin_event(h, "viterbi", sv);
+                if (tsplit && split_auto) {
+                    for (auto &e : h->split_ev) if (!e) HIPCHK(h, hipEventCreate(&e));
+                    HIPCHK(h, hipEventRecord(h->split_ev[0], sv));
+                }
                 hipError_t ve = tsplit ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, d_lock_order, n_lock, sv)
                                        : launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
+                if (tsplit && split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sv));
                 end_event(h, sv);
                 if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
                 if (tsplit) {
-                    h->split_checks.push_back({pass_index & 1, p, nc, split_auto, (double)maxF * (t.half_width == 25 ? 3.1e-6 : 7.3e-6)});
+                    h->split_checks.push_back({pass_index & 1, p, nc, split_auto, std::max((double)maxF * (t.half_width == 25 ? 3.1e-6 : 7.3e-6), (double)fp * 43e-9),
+                                               0.75 * (double)fp * 43e-9});
                     ++h->split_stats[0]; h->split_stats[1] += n_seg;
                 }
             }
@@ -2017,6 +2035,8 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "split_flagged_clips") return h->split_stats[2];
     if (n == "split_unlocked_clips") return h->split_stats[3];
     if (n == "split_carried_steps") return h->last_carried_steps;
+    if (n == "split_viterbi_us") return (int64_t)(h->last_split_viterbi_ms * 1e3);
+    if (n == "split_cooldown") return h->split_cooldown;
     if (n == "last_chunks") return h->last_chunks;
     if (n == "last_dense") return h->last_dense;
     if (n == "last_proportional") return h->last_proportional;

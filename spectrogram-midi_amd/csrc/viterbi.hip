@@ -360,18 +360,27 @@ __global__ __launch_bounds__(1024) void viterbi_band_split_kernel(PassParams p, 
 //   2. lock-on runs: segment k starts again at its boundary, now from the END column of segment k - 1, and runs until its
 //      column differs from the stored speculative column by a constant (spread of the differences <= sigma): usually at
 //      the first check, 16 steps in.  Its pointers replace the speculative ones up to there;
+//   2b. carry-on runs: a lock-on run that reaches the end of its segment without meeting the speculative run IS the
+//      sequential run up to there.  It happens where the recurrence has nothing to forget with: in a stretch without a voiced
+//      note the unvoiced states of the two edge bins (highest stay probability: the transition window is truncated there) run
+//      as two rails that never exchange paths, and the offset the last note left between them stays for good -- a run
+//      started from a guess inside the stretch cannot know it.  The clip's first such segment carries on from its exact
+//      column through the following segments until it is past the last of them and meets the stored column, or to the end
+//      of the clip (viterbi_band.inc, phase 3);
 //   3. stitch: per-segment pointer maps (state at the segment's end -> state at its boundary), composed per clip from
 //      the last segment's arg-max down, then the usual back-trace inside every segment, all in parallel;
-//   4. verification: float64 sums are not translation invariant, so a decision of the hybrid run can differ from the
-//      sequential run's where two candidates are closer than the accumulated rounding bound (and they are, exactly or
-//      nearly: two steps of an unvoiced walk commute, (X + k[a]) + k[c] against (X + k[c]) + k[a]).  Every state a path
-//      within that bound of the optimum can occupy is enumerated backwards from each such decision on the decoded path
-//      (the "tube"), until the tube collapses onto the path again: the decode is certified when, at every frame, the tube
-//      holds unvoiced states only or one single state -- then every near-optimal path, the sequential run's included, has
-//      the same voiced flags and the same voiced bins.  A clip that cannot be certified (or whose segment never locked on)
-//      is flagged and redone by the sequential kernel.
-// Outputs are therefore those of the sequential kernel by proof, not by luck; the unvoiced BIN of an unvoiced frame, which
-// no output carries, may differ.
+//   4. verification and exact resolution: float64 sums are not translation invariant, so a decision of the hybrid run can
+//      differ from the sequential run's where two candidates are closer than the accumulated rounding bound (and they are,
+//      exactly or nearly: two steps of an unvoiced walk commute, (X + k[a]) + k[c] against (X + k[c]) + k[a]).  Every state
+//      a path within that bound of the optimum can occupy is enumerated backwards from each such decision on the decoded
+//      path (the "tube") until the tube collapses onto the path again, and recorded; tubes that do not collapse (the two
+//      rails of an unvoiced stretch, tied for its whole length) are scanned in parallel and recorded as one entry.  One
+//      wave per clip then walks the path forwards carrying the sequential run's EXACT value of the path's state -- two
+//      float64 additions per frame outside the tubes, the sequential recurrence over the tube's states with the sequential
+//      kernel's tie rule inside them -- and re-traces the path through the exact pointers.  A clip that cannot be
+//      resolved (a tube wider or deeper than a record, an out-of-band candidate inside the bound) is flagged and redone
+//      by the sequential kernel.
+// Outputs are therefore those of the sequential kernel by construction, not by luck.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void viterbi_segmap_kernel(PassParams p) {
     constexpr int C = kViterbiChunk;

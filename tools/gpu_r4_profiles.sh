@@ -24,4 +24,9 @@ python3 /root/repo/tools/summarize_sq.py 2 $O/sq_counters_folder.json "$A" "$B" 
 cd /root/repo
 timeout -k 10 300 python bench.py --config shard --steps 10 --warmup 3 --no-cpu-baseline > $O/bench_shard.json 2> $O/bench_shard.err; echo "shard rc=$?"; cut -c1-200 $O/bench_shard.json
 timeout -k 10 300 python bench.py --config cqt --steps 5 --warmup 2 > $O/bench_cqt.json 2> $O/bench_cqt.err; echo "cqt rc=$?"; cut -c1-200 $O/bench_cqt.json
+# the time-split Viterbi: one clip, the tonal variant of a rank's shard, every rank's shard under the automatic rule
+timeout -k 10 500 python tools/bench_split.py single rank8tonal ranks > $O/split_bench.log 2> $O/split_bench.err; echo "split rc=$?"; grep -c "^{" $O/split_bench.log
+timeout -k 10 200 python tools/tube_survey.py 768 > $O/tube_survey.txt 2>&1; echo "tube survey rc=$?"; tail -1 $O/tube_survey.txt
+timeout -k 10 300 python tools/bench_v2_engine.py > $O/v2_engine.json 2> $O/v2_engine.err; echo "v2 rc=$?"; tail -c 300 $O/v2_engine.json
+AEGIS_HIP_LIB=/root/repo/_ablate/lib_abcqunc8.so timeout -k 10 200 python tools/cqt_cycles.py > $O/cqt_cycles.txt 2>&1; echo "cqt cycles rc=$?"
 ls -la $O
