@@ -319,7 +319,10 @@ int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64
  * "n_lags","n_pitch_bins","transition_width","n_trans_classes","max_frames_per_pass",
  * "lag_stride","yin_stride","obs_stride","last_frames","pyin_init"}; of the last call (its last pass): "last_passes",
  * "last_chunks", "last_dense", "last_proportional", "last_balanced", "last_persistent", "last_split_segments"; since create:
- * "split_passes", "split_segments", "split_flagged_clips", "split_unlocked_clips" (time-split Viterbi, csrc/viterbi.hip). */
+ * "split_passes", "split_segments", "split_flagged_clips" (clips the sequential kernel decoded again), "split_unlocked_clips";
+ * of the last split pass: "split_carried_steps" (longest carry-on run), "split_viterbi_us" (measured time of its Viterbi
+ * kernels, automatic passes only), "split_cooldown" (calls left that plan sequentially after split passes that did not pay)
+ * -- the time-split Viterbi, csrc/viterbi.hip. */
 int64_t aegis_get_param(const aegis_handle *h, const char *name);
 
 /* Copies an intermediate of the most recent pass (device -> host), for stage-level
