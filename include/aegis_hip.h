@@ -335,6 +335,8 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name);
  * because all their targets were dead at an easy frame (bench.py reports the ratios).
  * "persistent_fallbacks" i64[1]: calls this handle repeated with one Viterbi launch per time chunk after its single
  * launch per pass gave up waiting for the frame stage (kernels serialised by a counter-collecting profiler, for one).
+ * "fail_allocs": test hook, makes the next `cap` workspace growths fail as hipMalloc would (the out-of-memory retry:
+ * an analyze call that cannot allocate halves max_frames_per_pass, down to 2^21 frames, and plans its passes again).
  * "throw_bad_alloc" / "throw_length_error" / "throw_runtime_error" / "throw_int": test hooks of the exception barrier
  * (the body throws; the call returns AEGIS_ERR_NOMEM / AEGIS_ERR_DEVICE like any other failure).
  * Profiling builds only (csrc/Makefile EXTRA=-DAEGIS_ABLATE=64|128, -DCQT_ABLATE=8; zeros otherwise):

@@ -74,6 +74,7 @@ struct aegis_handle {
     hipEvent_t copy_event = nullptr;
     std::vector<hipEvent_t> sync_events;      // cross-stream dependencies (no timing)
     int64_t max_frames_per_pass = 0;
+    int fail_allocs = 0;                             // test hook: workspace growths left to fail with AEGIS_ERR_NOMEM
     mutable std::string err;
     std::vector<void *> table_allocs;
     // workspaces (grow-only): passes alternate between the two, so that the frame stage of one pass runs under the
@@ -164,6 +165,11 @@ namespace {
 
 int ensure(aegis_handle *h, DevBuf &b, size_t bytes) {
     if (bytes <= b.cap) return AEGIS_OK;
+    if (h->fail_allocs > 0) {                        // test hook (aegis_debug_fetch "fail_allocs"): the next growths fail as hipMalloc would
+        --h->fail_allocs;
+        h->err = "hipMalloc(" + std::to_string(bytes) + " bytes): out of memory (test hook)";
+        return AEGIS_ERR_NOMEM;
+    }
     if (b.p) {
         HIPCHK(h, hipDeviceSynchronize());          // kernels on any of the pipeline's streams may still use the old block
         HIPCHK(h, hipFree(b.p));
@@ -2083,6 +2089,7 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
     if (n == "throw_length_error") throw std::length_error("test hook");
     if (n == "throw_runtime_error") throw std::runtime_error("test hook: runtime_error");
     if (n == "throw_int") throw 42;
+    if (n == "fail_allocs") { h->fail_allocs = (int)std::max<int64_t>(0, cap); return 0; }      // (count in `cap`, nothing copied)
     const int64_t F = h->last_frames;
     const void *src = nullptr;
     int64_t count = 0;

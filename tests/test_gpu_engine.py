@@ -744,6 +744,34 @@ def test_time_split_on_one_rank_of_the_folder(monkeypatch):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
 
 
+def test_out_of_memory_retry_halves_the_passes():
+    """An analyze call whose workspace cannot be allocated (another handle or the caller took the memory the pass size was
+    derived from) halves max_frames_per_pass -- down to 2^21 frames -- and plans its passes again instead of failing: the first
+    workspace growth of a fresh handle fails through the test hook, the call succeeds with the same results, the pass size is
+    halved; at the floor the error comes out as AEGIS_ERR_NOMEM and the handle stays usable."""
+    clips = [signals.guitar_clip(6.0 + i, seed=40 + i) for i in range(3)]
+    ref_h = _lib.Handle()
+    want = _analyze_on_device(ref_h, clips)
+    ref_h.close()
+    h = _lib.Handle()
+    before = h.param("max_frames_per_pass")
+    assert before > 2 ** 21
+    h.lib.aegis_debug_fetch(h._h, b"fail_allocs", None, 1)
+    got = _analyze_on_device(h, clips)
+    assert h.param("max_frames_per_pass") == max(2 ** 21, before // 2)
+    for k in want:
+        np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+    h.close()
+    h = _lib.Handle(max_frames_per_pass=2 ** 21)
+    h.lib.aegis_debug_fetch(h._h, b"fail_allocs", None, 1)
+    with pytest.raises(_lib.AegisError) as ei:
+        _analyze_on_device(h, clips)
+    assert ei.value.code == _lib.ERR_NOMEM
+    got = _analyze_on_device(h, clips)
+    np.testing.assert_array_equal(got["f0"], want["f0"])
+    h.close()
+
+
 def test_graft_entry_smoke():
     """The driver's smoke() hook itself: one small analyze on cuda:0 checked against the oracle."""
     import __graft_entry__ as g
