@@ -106,7 +106,7 @@ struct aegis_handle {
     // time-split passes (viterbi.hip): AEGIS_TIME_SPLIT=<steps per segment> forces them, 0 turns them off, unset = when a pass
     // is bound by the recurrence of its longest clip
     int64_t split_seglen = -1;                // -1: automatic
-    int split_warmup = 128;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary
+    int split_warmup = 256;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary (128: lock-on after a median of 104 steps and one run in twenty never; 256: at the first check)
     struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; double t_front; };
     hipEvent_t split_ev[2] = {nullptr, nullptr};   // around an automatic split pass's Viterbi kernels: the planning rule checks its estimate against them
     int split_cooldown = 0;                   // automatic mode: calls left without time-split passes after one that did not pay (clips redone sequentially)
@@ -114,7 +114,7 @@ struct aegis_handle {
     int64_t split_stats[4] = {0, 0, 0, 0};    // since create: split passes, segments, clips flagged for the sequential kernel, lock-on runs that never locked
     int last_split_segments = 0;
     double last_split_viterbi_ms = 0.0;      // measured Viterbi time of the call's last automatic split pass
-    int64_t last_carried_steps = 0;          // longest carry-on run (viterbi_band.inc, phase 3) of the call's last split pass
+    int64_t last_carried_steps = 0;          // rounds of second speculation (viterbi_band.inc, phases 3 / 4) that had work in the call's last split pass
     std::vector<int64_t> last_split_flags;   // per clip of the call's last split pass (pass order: longest first): the verification's verdict bits
     int last_passes = 0, last_chunks = 0, last_dense = 0, last_proportional = 0, last_balanced = 0, last_persistent = 0;   // of the last call (its last pass)
     // profiling
@@ -604,10 +604,10 @@ static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
         HIPCHK(h, hipMemcpy(counts, sc.p.tube_count, 8, hipMemcpyDeviceToHost));
         h->last_carried_steps = counts[1];
         // The planning rule's estimate against the clock.  A split pass's Viterbi kernels come behind its frame stage, and their
-        // time depends on the material: a lock-on run that never meets the speculative one runs its whole segment and a carry-on
-        // run (the sequential recurrence, viterbi_band.inc phase 3) behind it; with a segment on every compute unit a step takes
-        // 5.5 us instead of 3.1.  When frame stage + measured Viterbi time is not clearly below what the pass would have taken
-        // sequentially, the next 32 calls of this handle plan their passes sequentially.
+        // time depends on the material: a lock-on run that never meets the speculative one runs its whole segment, and the
+        // segments behind it speculate again (one more segment time per round); with a segment on every compute unit a step
+        // takes 5.5 us instead of 3.1.  When frame stage + measured Viterbi time is not clearly below what the pass would have
+        // taken sequentially, the next 32 calls of this handle plan their passes sequentially.
         if (sc.automatic && h->split_ev[1]) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, h->split_ev[0], h->split_ev[1]) == hipSuccess) {
@@ -976,7 +976,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             if (proportional) ENS(clip_tb, (size_t)(nk + 1) * nc * 8);
             if (tsplit) {
                 ENS(seg64, m.seg64.size() * 8); ENS(seg32, m.seg32.size() * 4);
-                ENS(seg_col, (size_t)2 * n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, (size_t)n_seg * 3 * 4);
+                ENS(seg_col, (size_t)2 * n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, ((size_t)n_seg * 3 + nc) * 4);
                 ENS(colhist, (size_t)fp * S * 8); ENS(colG, (size_t)fp * 8); ENS(colkg, (size_t)fp * 4); ENS(clip_flag, (size_t)nc * 4);
                 ENS(flag_order, (size_t)nc * 4);
                 tube_cap = (int)std::max<int64_t>(4096, fp / 128);
@@ -997,10 +997,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         if (tsplit) {
             HIPCHK(h, hipMemcpyAsync(w.seg64.p, m.seg64.data(), m.seg64.size() * 8, hipMemcpyHostToDevice, fa));
             HIPCHK(h, hipMemcpyAsync(w.seg32.p, m.seg32.data(), m.seg32.size() * 4, hipMemcpyHostToDevice, fa));
-            HIPCHK(h, hipMemsetAsync(w.seg_i32.p, 0, (size_t)n_seg * 3 * 4, fa));       // seg_lock = 0 for the segments without a lock-on run
+            HIPCHK(h, hipMemsetAsync(w.seg_i32.p, 0, ((size_t)n_seg * 3 + nc) * 4, fa));       // seg_lock = 0 for the segments without a lock-on run
             HIPCHK(h, hipMemsetAsync(w.clip_flag.p, 0, (size_t)nc * 4, fa));
             HIPCHK(h, hipMemsetAsync(w.tube_at.p, 0, (size_t)fp * 4, fa));
-            HIPCHK(h, hipMemsetAsync(w.tube_count.p, 0, 8, fa));       // tubes recorded, longest carry-on run (steps)
+            HIPCHK(h, hipMemsetAsync(w.tube_count.p, 0, 8, fa));       // tubes recorded, rounds of second speculation that had work
         }
         PassParams p = base_params(t);
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
@@ -1068,7 +1068,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             d_seg_order = g32 + 4 * n_seg + nc + 1; d_lock_order = d_seg_order + n_seg;
             p.seg_col = static_cast<double *>(w.seg_col.p); p.seg_col2 = p.seg_col + (size_t)n_seg * S;
             p.seg_map = static_cast<uint16_t *>(w.seg_map.p);
-            p.seg_kg = static_cast<int32_t *>(w.seg_i32.p); p.seg_lock = p.seg_kg + n_seg; p.seg_end = p.seg_kg + 2 * n_seg;
+            p.seg_kg = static_cast<int32_t *>(w.seg_i32.p); p.seg_lock = p.seg_kg + n_seg; p.seg_end = p.seg_kg + 2 * n_seg; p.clip_first = p.seg_kg + 3 * n_seg;
             p.colhist = static_cast<double *>(w.colhist.p); p.colG = static_cast<double *>(w.colG.p); p.colkg = static_cast<int32_t *>(w.colkg.p);
             p.clip_flag = static_cast<uint32_t *>(w.clip_flag.p);
             p.tube_buf = static_cast<int32_t *>(w.tube_buf.p); p.tube_cap = tube_cap; p.tube_count = static_cast<uint32_t *>(w.tube_count.p);
@@ -2040,7 +2040,7 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "split_segments") return h->split_stats[1];
     if (n == "split_flagged_clips") return h->split_stats[2];
     if (n == "split_unlocked_clips") return h->split_stats[3];
-    if (n == "split_carried_steps") return h->last_carried_steps;
+    if (n == "split_rounds") return h->last_carried_steps;
     if (n == "split_viterbi_us") return (int64_t)(h->last_split_viterbi_ms * 1e3);
     if (n == "split_cooldown") return h->split_cooldown;
     if (n == "last_chunks") return h->last_chunks;

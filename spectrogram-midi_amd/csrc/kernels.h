@@ -98,9 +98,10 @@ struct PassParams {
     const int32_t *seg_clip;     // [n_seg] its clip (index into the pass)
     const int32_t *clip_seg0;    // [n_clips + 1] first segment of each clip
     double *seg_col;             // [n_seg][2 n_bins] end column of the speculative run
-    double *seg_col2;            // [n_seg][2 n_bins] end column of a lock-on run that never met the speculative one (phase 3 carries on from it)
+    double *seg_col2;            // [n_seg][2 n_bins] end column of a lock-on run that never met the speculative one (the next round speculates from it)
+    int32_t *clip_first;         // [n_clips] the clip's first segment whose lock-on run never met (this round; -1: none)
     int32_t *seg_kg;             // [n_seg] its arg-max
-    int32_t *seg_lock;           // [n_seg] local step at which the lock-on run met the speculative run, -1: it did not, -2: it did not and a carry-on run went through
+    int32_t *seg_lock;           // [n_seg] local step at which the lock-on run met the speculative run, -1: it did not, -2: it did not and a later round started over from its end column
     int32_t *seg_end;            // [n_seg] decoded state at the segment's last frame (stitch)
     uint16_t *seg_map;           // [n_seg][2 n_bins] state at the segment's last frame -> state at its boundary frame
     double *colhist;             // [F][2 n_bins] the column of every stored frame (lock-on comparison, verification)

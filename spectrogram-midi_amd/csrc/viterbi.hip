@@ -360,13 +360,15 @@ __global__ __launch_bounds__(1024) void viterbi_band_split_kernel(PassParams p, 
 //   2. lock-on runs: segment k starts again at its boundary, now from the END column of segment k - 1, and runs until its
 //      column differs from the stored speculative column by a constant (spread of the differences <= sigma): usually at
 //      the first check, 16 steps in.  Its pointers replace the speculative ones up to there;
-//   2b. carry-on runs: a lock-on run that reaches the end of its segment without meeting the speculative run IS the
-//      sequential run up to there.  It happens where the recurrence has nothing to forget with: in a stretch without a voiced
-//      note the unvoiced states of the two edge bins (highest stay probability: the transition window is truncated there) run
-//      as two rails that never exchange paths, and the offset the last note left between them stays for good -- a run
-//      started from a guess inside the stretch cannot know it.  The clip's first such segment carries on from its exact
-//      column through the following segments until it is past the last of them and meets the stored column, or to the end
-//      of the clip (viterbi_band.inc, phase 3);
+//   2b. rounds of second speculation: a lock-on run that reaches the end of its segment without meeting the speculative run
+//      IS the sequential run up to there.  It happens where the recurrence has nothing to forget with: in a stretch without
+//      a voiced note the unvoiced states of the two edge bins (highest stay probability: the transition window is truncated
+//      there) run as two rails that never exchange paths, and the offset the last note left between them stays for good -- a
+//      run started from the first-frame formula inside the stretch cannot know it (or, simply, the segment was shorter than
+//      the convergence took).  The run's last column is the best guess there is for what follows (in a stretch without
+//      information the column's shape is stationary): the next segment runs from it directly, the later segments of the
+//      clip speculate again from it and lock on again (viterbi_band.inc phases 3 / 4, kSplitRounds rounds; one more segment
+//      time per round instead of the rest of the clip in sequence);
 //   3. stitch: per-segment pointer maps (state at the segment's end -> state at its boundary), composed per clip from
 //      the last segment's arg-max down, then the usual back-trace inside every segment, all in parallel;
 //   4. verification and exact resolution: float64 sums are not translation invariant, so a decision of the hybrid run can
@@ -393,12 +395,23 @@ __global__ __launch_bounds__(1024) void viterbi_segmap_kernel(PassParams p) {
         for (int cc = (T - 2) / C; cc >= st / C; --cc) s = cmap[(int64_t)cc * S + s];
     p.seg_map[(int64_t)sg * S + j] = (uint16_t)s;
 }
+// Between the rounds of a time-split pass: the first segment of every clip whose lock-on run never met its speculative run
+// (-1) becomes the round's starting point and is marked -2; tube_count[1] keeps the number of rounds that had work.
+__global__ __launch_bounds__(64) void viterbi_round_kernel(PassParams p, int round) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= p.n_clips) return;
+    int k = -1;
+    for (int sg = p.clip_seg0[c] + 1; sg < p.clip_seg0[c + 1]; ++sg)
+        if (p.seg_lock[sg] == -1) { k = sg; break; }
+    p.clip_first[c] = k;
+    if (k >= 0) { p.seg_lock[k] = -2; atomicMax(p.tube_count + 1, (uint32_t)(round + 1)); }
+}
 __global__ __launch_bounds__(64) void viterbi_stitch_kernel(PassParams p) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= p.n_clips) return;
     const int S = 2 * p.n_bins, a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
     bool bad = false;
-    for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] == -1;      // (-2: a carry-on run replaced it by the sequential run)
+    for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] == -1;      // (-2: a later round started over from its end column)
     int e = p.seg_kg[b - 1];
     for (int k = b - 1; k >= a; --k) { p.seg_end[k] = e; e = p.seg_map[(int64_t)k * S + e]; }
     p.states[p.frame_off[c]] = e;
@@ -891,6 +904,7 @@ void launch_chunk_signal(uint32_t *flag, uint32_t gen, hipStream_t s) {
     hipLaunchKernelGGL(chunk_signal_kernel, dim3(1), dim3(1), 0, s, flag, gen);
 }
 
+constexpr int kSplitRounds = 2;
 static bool band_geometry(const PassParams &p);
 bool viterbi_split_applies(const PassParams &p, const DevTables &t) {
     return viterbi_band_applies(p, t) && p.width <= 128;
@@ -912,8 +926,15 @@ static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, 
     if (n_lock > 0) {
         q.split_phase = 2; q.order = lock_order;
         hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
-        q.split_phase = 3;                // carry-on runs: a workgroup returns at once unless its lock-on run never met the speculative one
-        hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
+        // rounds of second speculation for the clips with a lock-on run that never met (viterbi_band.inc): workgroups of
+        // clips without one return at once.  What is still unmet after the last round flags its clip (stitch kernel).
+        for (int round = 0; round < kSplitRounds; ++round) {
+            hipLaunchKernelGGL(viterbi_round_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, q, round);
+            q.split_phase = 3;
+            hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
+            q.split_phase = 4;
+            hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
+        }
     }
     return hipGetLastError();
 }

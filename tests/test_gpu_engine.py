@@ -715,7 +715,7 @@ def test_time_split_on_one_rank_of_the_folder(monkeypatch):
     """Rank 0's shard of BASELINE.json configs[3] on 8 GPUs (64 ragged clips of 81 .. 328 s: tonal, polyphonic and noisy ones;
     1.04 M frames) with the time split forced on every clip: 250-odd concurrent segments, thousands of tubes resolved by the
     exact walk, the noisy clips (unvoiced throughout: the two edge bins' unvoiced states tie for the whole clip) resolved
-    through rails and carry-on runs instead of being handed back to the sequential kernel -- and every output array equal
+    through rails and rounds of second speculation instead of being handed back to the sequential kernel -- and every output array equal
     to the sequential pass's, bit for bit."""
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -737,7 +737,7 @@ def test_time_split_on_one_rank_of_the_folder(monkeypatch):
     assert flagged <= 2 and v[12] > 2000 and v[13] > 500                 # tubes resolved by the exact walk; the path changed in many
     assert v[14] >= 1 and v[15] > 10000                                  # rails: tubes as long as an unvoiced clip, scanned in parallel
     lock = h.debug_fetch("seg_lock")
-    assert (lock != -1).all()                                            # a lock-on run that never met the speculative one was carried on
+    assert (lock != -1).all()                                            # a lock-on run that never met its speculative run was followed by a round of second speculation
     h.close()
     monkeypatch.delenv("AEGIS_TIME_SPLIT")
     for k in ref:

@@ -15,7 +15,10 @@ which = sys.argv[1:] or ["single", "rank8", "shard"]
 dev = torch.device("cuda", 0)
 
 
-def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", None)), kinds=None):
+FORCE = os.environ.get("BENCH_SPLIT_FORCE")          # segment length: the time split forced on every pass (no planning rule, no back-off)
+
+
+def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", FORCE)), kinds=None):
     n = np.array([len(c) for c in clips], np.int64)
     off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
     F = int((n // 512 + 1).sum())

@@ -34,7 +34,7 @@ for sl, wu in [(0, 128), (768, 128), (768, 256), (768, 384), (512, 128), (512, 2
     lk = h.debug_fetch("seg_lock") if sl else np.zeros(0)
     lkp = lk[lk > 0]
     print(json.dumps({"seglen": sl, "warmup": wu, "ms": round(float(np.median(ts[2:])) * 1e3, 3), "viterbi_ms": round(h.kernel_ms("viterbi"), 3),
-                      "segments": h.param("last_split_segments"), "redo": h.param("split_flagged_clips"), "carried_steps": h.param("split_carried_steps"),
+                      "segments": h.param("last_split_segments"), "redo": h.param("split_flagged_clips"), "rounds": h.param("split_rounds"),
                       "lock_median": float(np.median(lkp)) if len(lkp) else None, "lock_max": int(lkp.max()) if len(lkp) else None,
                       "never_or_carried": int((lk < 0).sum()), "equal": bool(same)}))
     h.close()
