@@ -711,6 +711,32 @@ def test_time_split_viterbi_equals_the_sequential_run(sr, monkeypatch):
     h.close()
 
 
+def test_time_split_rounds_of_second_speculation(monkeypatch):
+    """Segments shorter than the recurrence takes to converge (512 steps, warm-up 128, a 180 s clip): some lock-on runs reach
+    the end of their segment without meeting the speculative run, the segments behind them speculate again from the exact
+    column that run left (viterbi_band.inc phases 3 / 4) -- and the outputs are still the sequential pass's, bit for bit,
+    without a clip handed back to the sequential kernel."""
+    y = signals.guitar_clip(180.0, seed=3)
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    h = _lib.Handle()
+    ref = _analyze_on_device(h, [y])
+    h.close()
+    rounds = []
+    for seglen, warmup in ((512, 128), (256, 256), (384, 256)):
+        monkeypatch.setenv("AEGIS_TIME_SPLIT", str(seglen))
+        monkeypatch.setenv("AEGIS_SPLIT_WARMUP", str(warmup))
+        h = _lib.Handle()
+        got = _analyze_on_device(h, [y])
+        assert h.param("last_split_segments") >= 30 and h.param("split_flagged_clips") == 0
+        rounds.append(h.param("split_rounds"))
+        lock = h.debug_fetch("seg_lock")
+        assert (lock != -1).all()
+        h.close()
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{k} at {seglen}/{warmup}")
+    assert max(rounds) >= 1, rounds
+
+
 def test_time_split_on_one_rank_of_the_folder(monkeypatch):
     """Rank 0's shard of BASELINE.json configs[3] on 8 GPUs (64 ragged clips of 81 .. 328 s: tonal, polyphonic and noisy ones;
     1.04 M frames) with the time split forced on every clip: 250-odd concurrent segments, thousands of tubes resolved by the
