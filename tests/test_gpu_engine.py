@@ -93,6 +93,11 @@ def test_audio_to_midi_batch_equals_the_per_clip_calls(eng, test_clips):
     bad[12345] = np.inf
     with pytest.raises(ValueError, match="not finite everywhere .clip 1, sample 12345"):
         eng.audio_to_midi_batch([test_clips["tiny"], bad])
+    for poison, where in ((-np.inf, 777), (np.nan, 40001)):          # the kernels' clamps are NaN-safe: the call comes back with the verdict
+        bad = test_clips["notes"].copy()
+        bad[where] = poison
+        with pytest.raises(ValueError, match=f"not finite everywhere .clip 0, sample {where}"):
+            eng.audio_to_midi_batch([bad, test_clips["tiny"]])
     r, e, b = eng.audio_to_midi_batch([test_clips["notes"]], want_midi=False, turbo_mode=True)
     ref = oengine.audio_to_midi(test_clips["notes"], turbo_mode=True, num_cores=eng.turbo_cores or os.cpu_count())
     assert_events_equal(e[0], oengine.extract_events(ref)) and b[0] is None
