@@ -734,6 +734,86 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
         const int *rec = rec_lds;
         const int D = rec[2], RA = rec[kRailAt], RL = RA >= 0 ? rec[kRailLen] : 0;
         const int64_t ttop = fc + rec[1];
+        // The common tube -- no rail, at most 15 levels of at most 4 states -- in registers: lane 4 d + q holds state q of level d.
+        // Every lane fetches its state's observation, its transition entries from the (<= 4) states of the level below and the
+        // path's old state in ONE batch of loads; the recurrence then runs level by level on cross-lane reads, and the new path
+        // goes back in one batch of stores.  (Level by level through global memory it was three dependent loads per level:
+        // ~20 us per tube, ~400 tubes in a polyphonic clip, one clip after the other.)
+        bool fast = RA < 0 && D <= 15;
+        {
+            const int nl = (lane <= D && lane < 16) ? rec[4 + lane * (1 + CAP)] : 0;
+            fast = fast && __ballot(nl > 4) == 0ull;
+        }
+        if (fast) {
+            const int d = lane >> 2, q = lane & 3;
+            const int *cs = rec + 4 + (d <= D ? d : D) * (1 + CAP);
+            const bool have = d <= D && q < cs[0];
+            const int j = have ? cs[1 + q] : 0;
+            const int *ps = rec + 4 + (d < D ? d + 1 : D) * (1 + CAP);
+            const int npd = (have && d < D) ? ps[0] : 0;
+            int si[4];
+            double lt[4];
+            bool inb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                si[i] = i < npd ? ps[1 + i] : 0;
+                inb[i] = i < npd && in_band(si[i], j);
+                lt[i] = inb[i] ? split_lt(p, tb, si[i], j) : 0.0;
+            }
+            const double ob = (have && d < D) ? split_obs(p, j, ttop - d) : 0.0;
+            const int old = lane <= D ? states[ttop - lane] : 0;          // (here the lane is the level)
+            double x = 0.0;
+            if (have && d == D) x = cs[0] == 1 ? X : p.seg_col[(int64_t)a * S + j];
+            int bidx = 0;
+            for (int dd = D - 1; dd >= 0; --dd) {
+                double xi[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xi[i] = __shfl(x, 4 * (dd + 1) + i);
+                if (have && d == dd) {
+                    double best = -INFINITY;
+                    int bs = 0x7fffffff;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (!inb[i]) continue;
+                        const double cand = xi[i] + lt[i];
+                        if (cand > best || (cand == best && si[i] < bs)) { best = cand; bs = si[i]; bidx = i; }
+                    }
+                    x = ob + best;
+                }
+            }
+            // the top: one state, or (last frame of the clip) the exact arg-max of the candidates, lowest state first
+            const int *ts = rec + 4;
+            int top = 0;
+            double xt = __shfl(x, 0);
+            for (int k = 1; k < ts[0]; ++k) {
+                const double xk = __shfl(x, k);
+                if (xk > xt || (xk == xt && ts[1 + k] < ts[1 + top])) { top = k; xt = xk; }
+            }
+            X = xt;
+            // the path through the tube by the exact pointers (uniform scalars), every level's new state to the lane of that level
+            int idx = top, mynew = old;
+            for (int dl = 0; dl <= D; ++dl) {
+                const int st = rec[4 + dl * (1 + CAP) + 1 + idx];
+                if (lane == dl) mynew = st;
+                if (dl < D) idx = __shfl(bidx, 4 * dl + idx);
+            }
+            const bool diff = lane <= D && mynew != old;
+            const unsigned long long dm = __ballot(diff);
+            if (diff && lane != D) states[ttop - lane] = mynew;
+            if ((dm >> D) & 1ull) {
+                // (a change at the bottom can only happen at the first boundary, where the bottom set holds several states: the path
+                // enters the exact run in another state -- follow the exact run's own pointers down until the old path is met)
+                if (lane == D) {
+                    int sx = mynew;
+                    int64_t tt = ttop - D;
+                    while (states[tt] != sx) { states[tt] = sx; if (tt == fc) break; sx = p.ptr[tt * (int64_t)S + sx]; --tt; }
+                }
+            }
+            if (lane == 0) { n_res += 1; n_chg += dm ? 1 : 0; }
+            __syncthreads();
+            t = ttop;
+            continue;
+        }
         {
             const int *bs = rec + 4 + D * (1 + CAP);                   // the bottom set: one state, or several at the first boundary
             if (lane < bs[0]) xv[0][lane] = bs[0] == 1 ? X : p.seg_col[(int64_t)a * S + bs[1 + lane]];
