@@ -106,6 +106,13 @@ struct aegis_handle {
     // time-split passes (viterbi.hip): AEGIS_TIME_SPLIT=<steps per segment> forces them, 0 turns them off, unset = when a pass
     // is bound by the recurrence of its longest clip
     int64_t split_seglen = -1;                // -1: automatic
+    // AEGIS_SPLIT_SEGMENT_ROUNDS: segments per compute unit the automatic rule plans for (whole rounds of workgroups).  The
+    // speculative runs take the same time in one round of long segments or two rounds of segments half as long (+ the second
+    // warm-up), but a lock-on run that never meets its speculative run costs a whole segment and a round of second speculation
+    // another: with two rounds of segments six of the folder's eight rank shards run in 77-79 ms instead of 91-99 (and the
+    // other two in 68-71 instead of 66).
+    int split_rounds_of_segments = 2;
+    int split_bad = 0;                        // automatic split passes in a row that did not pay (two of them start the cool-down)
     int split_warmup = 256;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary (128: lock-on after a median of 104 steps and one run in twenty never; 256: at the first check)
     struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; double t_front; };
     hipEvent_t split_ev[2] = {nullptr, nullptr};   // around an automatic split pass's Viterbi kernels: the planning rule checks its estimate against them
@@ -328,6 +335,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CMND_IN_FRAME")) h->cmnd_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_TROUGHS_IN_FRAME")) h->troughs_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_TIME_SPLIT")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_seglen = v / kViterbiChunk * kViterbiChunk; }
+    if (const char *e = std::getenv("AEGIS_SPLIT_SEGMENT_ROUNDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) h->split_rounds_of_segments = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_WARMUP")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_warmup = (int)(v / kViterbiChunk * kViterbiChunk); }
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
     if (const char *e = std::getenv("AEGIS_CHUNK_GROWTH")) { const long v = std::strtol(e, nullptr, 10); if (v >= 100 && v <= 400) h->chunk_growth_pct = (int)v; }
@@ -612,7 +620,8 @@ static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, h->split_ev[0], h->split_ev[1]) == hipSuccess) {
                 h->last_split_viterbi_ms = ms;
-                if (sc.t_front + 1e-3 * ms > 0.92 * sc.t_seq) h->split_cooldown = 32;
+                if (sc.t_front + 1e-3 * ms > 0.92 * sc.t_seq) { if (++h->split_bad >= 2) { h->split_cooldown = 32; h->split_bad = 0; } }
+                else h->split_bad = 0;
             }
         }
         if (redo.empty()) continue;
@@ -792,13 +801,14 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 // work if that is more (they overlap); split pass: the frame stage first (3/4 of the work, not overlapped),
                 // then one segment + warm-up + a typical lock-on tail, stitch and verification.
                 const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, work = (double)fp * 43e-9;
-                int64_t sl = std::max<int64_t>(768, ((fp - nc) / std::max(1, h->n_cus) + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                const int seg_budget = std::max(1, h->n_cus) * h->split_rounds_of_segments;
+                int64_t sl = std::max<int64_t>(768, ((fp - nc) / seg_budget + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
                 // one workgroup per segment, one per compute unit: a 257th segment would run alone after the other 256
                 // (rank 0 of the folder on 8 GPUs: 258 segments, speculative runs 24.0 ms instead of 13)
                 for (int guard = 0; guard < 64; ++guard) {
                     int64_t ns = 0;
-                    for (int i = 0; i < nc; ++i) ns += std::max<int64_t>(1, (frames[pc[i]] - 1 + sl / 2) / sl);
-                    if (ns <= h->n_cus) break;
+                    for (int i = 0; i < nc; ++i) ns += std::max<int64_t>(1, (frames[pc[i]] - 1 + sl - 1) / sl);
+                    if (ns <= seg_budget) break;
                     sl = (sl + sl / 32 + kViterbiChunk) / kViterbiChunk * kViterbiChunk;
                 }
                 const double t_seq = std::max((double)maxF * step, work);
@@ -814,7 +824,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             std::vector<int32_t> sT, sst, sprev, sclip, cseg0(nc + 1, 0);
             for (int i = 0; i < nc; ++i) {
                 const int64_t Fc = frames[pc[i]], steps = Fc - 1;
-                const int ns = (int)std::max<int64_t>(1, (steps + seglen / 2) / seglen);
+                // (ceil: no segment longer than seglen -- the launch lasts as long as its longest segment; with rounding a clip of
+                // 1.49 segment lengths ran as ONE segment and set the pace of the whole launch)
+                const int ns = (int)std::max<int64_t>(1, (steps + seglen - 1) / seglen);
                 cseg0[i] = n_seg;
                 int64_t mprev = 0;
                 for (int k = 0; k < ns; ++k) {

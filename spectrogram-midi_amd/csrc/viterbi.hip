@@ -539,7 +539,21 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
         const bool oob = (bg > b2 ? bg - b2 : b2 - bg) > H;
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) best = fmax(best, __shfl_xor(best, o));
-        if (oob && G + p.log_tiny >= best - thr) why = why ? why : 9;     // the out-of-band candidate in play: not handled
+        // The one out-of-band candidate (the previous column's arg-max at log tiny: viterbi_band.inc) joins the set when it is
+        // within the bound of the best -- a hard frame whose observed bins lie far from the path: jump at log tiny, or stay and
+        // take a log tiny observation.  Its source is the column's arg-max, which has to be beyond doubt: a second state within
+        // the bound of the column maximum flags the clip.
+        if (oob && G + p.log_tiny >= fmax(best, G + p.log_tiny) - thr) {
+            best = fmax(best, G + p.log_tiny);
+            int cnt = 0;
+            for (int j0 = 0; j0 < S; j0 += 64) cnt += __popcll(__ballot(j0 + lane < S && col[j0 + lane] >= G - thr));
+            if (cnt > 1) why = why ? why : 9;
+            else {
+                bool have = false;
+                for (int q = 0; q < n; ++q) have |= dst[q] == kg;
+                if (!have) { if (n < CAP) dst[n++] = kg; else why = why ? why : 3; }
+            }
+        }
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
@@ -754,11 +768,13 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
             int si[4];
             double lt[4];
             bool inb[4];
+            const int kgp = (have && d < D) ? p.colkg[ttop - d - 1] : -1;     // the one source allowed out of band: the column arg-max below
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 si[i] = i < npd ? ps[1 + i] : 0;
-                inb[i] = i < npd && in_band(si[i], j);
-                lt[i] = inb[i] ? split_lt(p, tb, si[i], j) : 0.0;
+                const bool band = i < npd && in_band(si[i], j);
+                inb[i] = band || (i < npd && si[i] == kgp);
+                lt[i] = band ? split_lt(p, tb, si[i], j) : p.log_tiny;
             }
             const double ob = (have && d < D) ? split_obs(p, j, ttop - d) : 0.0;
             const int old = lane <= D ? states[ttop - lane] : 0;          // (here the lane is the level)
@@ -858,10 +874,12 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
                 const int j = cs[1 + lane];
                 double best = -INFINITY;
                 int bs = 0x7fffffff, bidx = 0;
+                const int kgp = p.colkg[fr - 1];                        // the one source allowed out of band: the column arg-max below
                 for (int i = 0; i < np; ++i) {
                     const int si = ps[1 + i];
-                    if (!in_band(si, j)) continue;
-                    const double cand = xv[pb][i] + split_lt(p, tb, si, j);
+                    const bool band = in_band(si, j);
+                    if (!band && si != kgp) continue;
+                    const double cand = xv[pb][i] + (band ? split_lt(p, tb, si, j) : p.log_tiny);
                     if (cand > best || (cand == best && si < bs)) { best = cand; bs = si; bidx = i; }
                 }
                 xv[pb ^ 1][lane] = split_obs(p, j, fr) + best;
