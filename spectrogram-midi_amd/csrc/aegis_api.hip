@@ -613,9 +613,9 @@ static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
         h->last_carried_steps = counts[1];
         // The planning rule's estimate against the clock.  A split pass's Viterbi kernels come behind its frame stage, and their
         // time depends on the material: a lock-on run that never meets the speculative one runs its whole segment, and the
-        // segments behind it speculate again (one more segment time per round); with a segment on every compute unit a step
-        // takes 5.5 us instead of 3.1.  When frame stage + measured Viterbi time is not clearly below what the pass would have
-        // taken sequentially, the next 32 calls of this handle plan their passes sequentially.
+        // segments behind it speculate again (one more segment time per round).  When frame stage + measured Viterbi time is
+        // not clearly below what the pass would have taken sequentially twice in a row, the next 32 calls of this handle plan
+        // their passes sequentially.
         if (sc.automatic && h->split_ev[1]) {
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, h->split_ev[0], h->split_ev[1]) == hipSuccess) {
