@@ -379,9 +379,10 @@ __global__ __launch_bounds__(1024) void viterbi_band_split_kernel(PassParams p, 
 //      rails of an unvoiced stretch, tied for its whole length) are scanned in parallel and recorded as one entry.  One
 //      wave per clip then walks the path forwards carrying the sequential run's EXACT value of the path's state -- two
 //      float64 additions per frame outside the tubes, the sequential recurrence over the tube's states with the sequential
-//      kernel's tie rule inside them -- and re-traces the path through the exact pointers.  A clip that cannot be
-//      resolved (a tube wider or deeper than a record, an out-of-band candidate inside the bound) is flagged and redone
-//      by the sequential kernel.
+//      kernel's tie rule inside them (the previous column's arg-max at log tiny, the one out-of-band source the kernels
+//      consider, included where it is within the bound) -- and re-traces the path through the exact pointers.  A clip that
+//      cannot be resolved (a tube wider or deeper than a record, a column arg-max in doubt where the out-of-band candidate
+//      is in play) is flagged and redone by the sequential kernel.
 // Outputs are therefore those of the sequential kernel by construction, not by luck.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void viterbi_segmap_kernel(PassParams p) {
@@ -459,7 +460,7 @@ __global__ __launch_bounds__(256) void viterbi_segtrace_kernel(PassParams p) {
 // and the sequential kernel decodes it again.
 // g_verify_dbg: [0] -, [1] tubes opened, [2] tubes recorded, then the reasons a clip was flagged: [3] tube wider
 // than kTubeCap, [5] tube closed on another state than the decoded one, [6] tube open at the exact run, [7] deeper than
-// kTubeDepth, [8] largest depth recorded, [9] out-of-band candidate within the bound, [10] last column's maximum not unique
+// kTubeDepth, [8] largest depth recorded, [9] out-of-band candidate within the bound while the column's arg-max is in doubt, [10] last column's maximum not unique
 // within the bound, [11] record buffer full, [12] tubes resolved by the exact walk, [13] of which changed the path,
 // [14] tubes with a rail, [15] frames those rails span
 //
