@@ -110,8 +110,8 @@ struct aegis_handle {
     // speculative runs take the same time in one round of long segments or two rounds of segments half as long (+ the second
     // warm-up), but a lock-on run that never meets its speculative run costs a whole segment and a round of second speculation
     // another: with two rounds of segments six of the folder's eight rank shards run in 77-79 ms instead of 91-99 (and the
-    // other two in 68-71 instead of 66).
-    int split_rounds_of_segments = 2;
+    // other two in 68-71 instead of 66); with three the slowest shard takes 76.7 ms instead of 79.5, with four 77.6.
+    int split_rounds_of_segments = 3;
     int split_bad = 0;                        // automatic split passes in a row that did not pay (two of them start the cool-down)
     int split_warmup = 256;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary (128: lock-on after a median of 104 steps and one run in twenty never; 256: at the first check)
     struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; double t_front; };
