@@ -112,6 +112,13 @@ struct aegis_handle {
     // another: with two rounds of segments six of the folder's eight rank shards run in 77-79 ms instead of 91-99 (and the
     // other two in 68-71 instead of 66); with three the slowest shard takes 76.7 ms instead of 79.5, with four 77.6.
     int split_rounds_of_segments = 3;
+    // AEGIS_SPLIT_SUB_PASSES=2: a split call of >= 16 clips runs as two passes of every second clip, the second half's frame
+    // stage under the first half's Viterbi kernels.  Measured on rank 0's shard of the folder (forced 1 536-step segments):
+    // 86.5 ms against 76.0 as one pass -- the latency-bound parts of a split pass (lock-on tail, rounds of second speculation,
+    // verification, exact walk: ~25 ms) do not shrink with half the clips and now run twice.  Off by default.
+    int split_sub_passes = 1;
+    bool call_split_started = false;          // this call's first automatic split pass has recorded split_ev[0]
+    double call_t_seq = 0.0, call_t_front = 0.0;   // the call's sequential estimate; the first split pass's frame stage (not overlapped)
     int split_bad = 0;                        // automatic split passes in a row that did not pay (two of them start the cool-down)
     int split_warmup = 256;                   // AEGIS_SPLIT_WARMUP: frames a speculative run starts ahead of its boundary (128: lock-on after a median of 104 steps and one run in twenty never; 256: at the first check)
     struct SplitCheck { int work; PassParams p; int nc; bool automatic; double t_seq; double t_front; };
@@ -119,7 +126,8 @@ struct aegis_handle {
     int split_cooldown = 0;                   // automatic mode: calls left without time-split passes after one that did not pay (clips redone sequentially)
     std::vector<SplitCheck> split_checks;     // split passes of the call in flight: their clip flags are read after the synchronisation
     int64_t split_stats[4] = {0, 0, 0, 0};    // since create: split passes, segments, clips flagged for the sequential kernel, lock-on runs that never locked
-    int last_split_segments = 0;
+    int last_split_segments = 0;              // of the last call (all its passes)
+    int last_pass_segments = 0;               // of its last pass (what the debug fetches of per-segment arrays index)
     double last_split_viterbi_ms = 0.0;      // measured Viterbi time of the call's last automatic split pass
     int64_t last_carried_steps = 0;          // rounds of second speculation (viterbi_band.inc, phases 3 / 4) that had work in the call's last split pass
     std::vector<int64_t> last_split_flags;   // per clip of the call's last split pass (pass order: longest first): the verification's verdict bits
@@ -335,6 +343,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_CMND_IN_FRAME")) h->cmnd_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_TROUGHS_IN_FRAME")) h->troughs_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_TIME_SPLIT")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_seglen = v / kViterbiChunk * kViterbiChunk; }
+    if (const char *e = std::getenv("AEGIS_SPLIT_SUB_PASSES")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 2) h->split_sub_passes = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_SEGMENT_ROUNDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) h->split_rounds_of_segments = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_WARMUP")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_warmup = (int)(v / kViterbiChunk * kViterbiChunk); }
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
@@ -616,11 +625,11 @@ static int split_check(aegis_handle *h, const Tables &t, hipStream_t s) {
         // segments behind it speculate again (one more segment time per round).  When frame stage + measured Viterbi time is
         // not clearly below what the pass would have taken sequentially twice in a row, the next 32 calls of this handle plan
         // their passes sequentially.
-        if (sc.automatic && h->split_ev[1]) {
+        if (sc.automatic && h->split_ev[1] && &sc == &h->split_checks.back()) {      // once per call: from its first split pass's Viterbi kernels to its last's
             float ms = 0.f;
             if (hipEventElapsedTime(&ms, h->split_ev[0], h->split_ev[1]) == hipSuccess) {
                 h->last_split_viterbi_ms = ms;
-                if (sc.t_front + 1e-3 * ms > 0.92 * sc.t_seq) { if (++h->split_bad >= 2) { h->split_cooldown = 32; h->split_bad = 0; } }
+                if (h->call_t_front + 1e-3 * ms > 0.92 * h->call_t_seq) { if (++h->split_bad >= 2) { h->split_cooldown = 32; h->split_bad = 0; } }
                 else h->split_bad = 0;
             }
         }
@@ -742,12 +751,68 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     // fixed slots of sync_events: 0 call start, 1/2 pass done (workspace parity), 3 frame_b joined, 4 frame_a final, 5.. per chunk
     enum { EV_START = 0, EV_DONE0 = 1, EV_DONE1 = 2, EV_FB = 3, EV_FA = 4, EV_META = 5, EV_CHUNK0 = 6 };
 
+    // ---- time-split planning (viterbi.hip "Time-split Viterbi") --------------------------------------------------------
+    // The Viterbi recurrence keeps one compute unit per clip for (frames of the clip) x 3.1 us; the rest of the path costs
+    // ~43 ns per frame of the whole chip.  A pass whose longest clip outlasts the work of the whole pass cuts its clips into
+    // segments that run concurrently (blocking calls on the handle's own stream only: the clips that cannot be certified are
+    // redone after the call's synchronisation).  plan_split: the segment length for a set of clips, 0 = stay sequential.
+    const bool split_ok = py && !stream_v && sync && h->split_seglen != 0 && viterbi_split_applies(base_params(t), h->dt);
+    bool split_cooling = false;
+    if (split_ok && h->split_seglen < 0 && h->split_cooldown > 0) { --h->split_cooldown; split_cooling = true; }
+    auto plan_split = [&](const int *clips_of_pass, int nc, int64_t fp, int64_t maxF, bool &automatic) -> int64_t {
+        automatic = false;
+        if (!split_ok || nc >= 256) return 0;
+        if (h->split_seglen > 0) return h->split_seglen;
+        if (split_cooling) return 0;
+        // automatic: when the estimate says so.  Sequential pass: the longest clip's recurrence, or the pass's whole work if
+        // that is more (they overlap); split pass: the frame stage first (3/4 of the work, not overlapped), then one segment +
+        // warm-up + a typical lock-on tail, stitch and verification.
+        const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, work = (double)fp * 43e-9;
+        const int seg_budget = std::max(1, h->n_cus) * h->split_rounds_of_segments;
+        int64_t sl = std::max<int64_t>(768, ((fp - nc) / seg_budget + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+        // whole rounds of workgroups: a 257th segment would run alone after the other 256
+        for (int guard = 0; guard < 64; ++guard) {
+            int64_t ns = 0;
+            for (int i = 0; i < nc; ++i) ns += std::max<int64_t>(1, (frames[clips_of_pass[i]] - 1 + sl - 1) / sl);
+            if (ns <= seg_budget) break;
+            sl = (sl + sl / 32 + kViterbiChunk) / kViterbiChunk * kViterbiChunk;
+        }
+        const double t_seq = std::max((double)maxF * step, work);
+        const double t_split = 0.75 * work + (double)(sl + h->split_warmup + 600) * step + 2.5e-3;
+        if (t_split < 0.8 * t_seq) { automatic = true; return sl; }
+        return 0;
+    };
+    // Sub-passes.  A split pass runs its frame stage IN FRONT of its segments (they need every frame's observations), and
+    // behind the speculative runs the lock-on runs, the verification and the exact walk keep only a few compute units busy.
+    // With AEGIS_SPLIT_SUB_PASSES=2 a call that would be one split pass of >= 16 clips is cut into two passes of every second
+    // clip (longest first in both): the second half's frame stage runs under the first half's Viterbi kernels, on the pass
+    // machinery that already overlaps pass k + 1's frame stage with pass k's Viterbi (two workspaces).  Measured slower (see
+    // split_sub_passes): kept as an experiment knob, off by default.
+    int sub_cut = 0;
+    h->call_split_started = false;
+    if (split_ok && h->split_sub_passes > 1 && n_clips >= 16 && n_clips < 256 && total_frames <= h->max_frames_per_pass) {
+        bool automatic = false;
+        if (plan_split(by_len.data(), n_clips, total_frames, frames[by_len[0]], automatic) > 0) {
+            std::vector<int> re;
+            re.reserve(n_clips);
+            for (int i = 0; i < n_clips; i += 2) re.push_back(by_len[i]);
+            sub_cut = (int)re.size();
+            for (int i = 1; i < n_clips; i += 2) re.push_back(by_len[i]);
+            by_len.swap(re);
+        }
+    }
+    h->call_t_seq = std::max((double)frames[by_len[0]] * (t.half_width == 25 ? 3.1e-6 : 7.3e-6), (double)total_frames * 43e-9);
+
     int first = 0, pass_index = 0;
     bool done_recorded[2] = {false, false};
     std::vector<hipStream_t> joined;          // streams whose work s must wait for before the call returns
     while (first < n_clips) {
         int last = first;
         int64_t fp = 0;
+        if (sub_cut > 0) {          // the two halves of a split call
+            last = first == 0 ? sub_cut : n_clips;
+            for (int i = first; i < last; ++i) fp += frames[by_len[i]];
+        } else
         while (last < n_clips && fp + frames[by_len[last]] <= h->max_frames_per_pass) { fp += frames[by_len[last]]; ++last; }
         const int nc = last - first;
         const int *pc = by_len.data() + first;            // this pass's clips (indices into the caller's arrays)
@@ -786,36 +851,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Viterbi launch that waits for a flag per chunk (64 clips x 180 s: 59.5 -> 50.8 ms).  With fewer clips the pass is
         // Viterbi-bound and the gain is the launches and the head (48 clips: 52.0 -> 50.2 ms, 16: 50.2 -> 50.0, 8: 49.5
         // -> 49.8), hence the lower limit; unpartitioned passes lose with small chunks.
-        // ---- time-split pass? (viterbi.hip "Time-split Viterbi") ------------------------------------------------
-        // The Viterbi recurrence keeps one compute unit per clip for (frames of the clip) x 3.1 us; the rest of the path
-        // costs ~43 ns per frame of the whole chip.  A pass whose longest clip outlasts the work of the whole pass cuts
-        // its clips into segments that run concurrently (blocking calls on the handle's own stream only: the clips that
-        // cannot be certified are redone after the call's synchronisation).
-        int64_t seglen = 0;
         bool split_auto = false;
-        if (py && !stream_v && sync && nc < 256 && h->split_seglen != 0 && viterbi_split_applies(base_params(t), h->dt)) {
-            if (h->split_seglen > 0) seglen = h->split_seglen;
-            else if (h->split_cooldown > 0) --h->split_cooldown;
-            else {
-                // automatic: when the estimate says so.  Sequential pass: the longest clip's recurrence, or the pass's whole
-                // work if that is more (they overlap); split pass: the frame stage first (3/4 of the work, not overlapped),
-                // then one segment + warm-up + a typical lock-on tail, stitch and verification.
-                const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, work = (double)fp * 43e-9;
-                const int seg_budget = std::max(1, h->n_cus) * h->split_rounds_of_segments;
-                int64_t sl = std::max<int64_t>(768, ((fp - nc) / seg_budget + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
-                // one workgroup per segment, one per compute unit: a 257th segment would run alone after the other 256
-                // (rank 0 of the folder on 8 GPUs: 258 segments, speculative runs 24.0 ms instead of 13)
-                for (int guard = 0; guard < 64; ++guard) {
-                    int64_t ns = 0;
-                    for (int i = 0; i < nc; ++i) ns += std::max<int64_t>(1, (frames[pc[i]] - 1 + sl - 1) / sl);
-                    if (ns <= seg_budget) break;
-                    sl = (sl + sl / 32 + kViterbiChunk) / kViterbiChunk * kViterbiChunk;
-                }
-                const double t_seq = std::max((double)maxF * step, work);
-                const double t_split = 0.75 * work + (double)(sl + h->split_warmup + 600) * step + 2.5e-3;
-                if (t_split < 0.8 * t_seq) { seglen = sl; split_auto = true; }
-            }
-        }
+        const int64_t seglen = py ? plan_split(pc, nc, fp, maxF, split_auto) : 0;
         const bool tsplit = seglen > 0;
         int n_seg = 0, n_lock = 0, tube_cap = 0;
         if (tsplit) {
@@ -949,7 +986,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v) ? split_streams(h, nc) : nullptr;
         hipStream_t fa = ss ? ss->frame_a : s;
         hipStream_t fb = ss ? ss->frame_b : h->stream4;
-        hipStream_t sv = ss ? ss->viterbi : ((py && nk > 1) ? h->stream2 : fa);
+        hipStream_t sv = ss ? ss->viterbi : ((py && (nk > 1 || tsplit)) ? h->stream2 : fa);      // (a split pass: the next pass's frame stage runs under its Viterbi kernels)
         // Large batches are frame-stage bound (every CU carries a Viterbi workgroup): alternating the chunks over two
         // streams lets chunk k+1's FFTs overlap chunk k's latency-bound observation kernel.  Small batches are
         // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
@@ -1156,7 +1193,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 begin_event(h, "viterbi", sv);
                 if (tsplit && split_auto) {
                     for (auto &e : h->split_ev) if (!e) HIPCHK(h, hipEventCreate(&e));
-                    HIPCHK(h, hipEventRecord(h->split_ev[0], sv));
+                    if (!h->call_split_started) { HIPCHK(h, hipEventRecord(h->split_ev[0], sv)); h->call_split_started = true; h->call_t_front = 0.75 * (double)fp * 43e-9; }
                 }
                 hipError_t ve = tsplit ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, d_lock_order, n_lock, sv)
                                        : launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
@@ -1185,7 +1222,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         done_recorded[pass_index & 1] = true;
         HIPCHK(h, hipGetLastError());
         h->last_frames = fp;
-        h->last_split_segments = tsplit ? n_seg : 0;
+        h->last_split_segments = (pass_index == 0 ? 0 : h->last_split_segments) + (tsplit ? n_seg : 0);      // of the call: all its passes
+        h->last_pass_segments = tsplit ? n_seg : 0;
         h->last_chunks = nk; h->last_dense = dense ? 1 : 0; h->last_proportional = proportional ? 1 : 0;
         h->last_balanced = balanced ? 1 : 0; h->last_persistent = persistent ? 1 : 0;
         h->last_work = pass_index & 1;
@@ -2170,8 +2208,8 @@ int64_t aegis_debug_fetch(aegis_handle *h, const char *name, void *dst, int64_t 
         return 24;
     }
     else if (n == "seg_lock") {           // lock-on run lengths of the last time-split pass, one per segment (0: first of its clip, -1: never met)
-        if (h->device < 0 || h->last_split_segments <= 0) return 0;
-        const int ns = h->last_split_segments;
+        if (h->device < 0 || h->last_pass_segments <= 0) return 0;
+        const int ns = h->last_pass_segments;
         if (dst && cap > 0) {
             std::vector<int32_t> v((size_t)ns), st((size_t)ns);
             HIPCHK(h, hipSetDevice(h->device));
