@@ -30,13 +30,14 @@ enum { TECH_NONE = 0, TECH_VIBRATO = 1, TECH_BEND = 2, TECH_SLIDE = 3, TECH_HAMM
 
 struct Fit { int code; double slope; bool risky; };
 
-// detect_articulations (midi_logic.py:6-30) for frames start..end inclusive, every frame sounding
-Fit fit_run(const double *semi, int64_t start, int64_t end) {
+// detect_articulations (midi_logic.py:6-30) for frames start..end inclusive, every frame sounding; semi(i) = the
+// semitone value of frame i (an array element, or the decoded bin's table entry: the same double either way)
+template <class Semi>
+Fit fit_run(const Semi &semi, int64_t start, int64_t end) {
     const int64_t n = end - start + 1;
     if (n < 3) return {TECH_NONE, 0.0, false};
-    const double *y = semi + start;
     double sy = 0.0, sxy = 0.0;
-    for (int64_t i = 0; i < n; ++i) { sy += y[i]; sxy += (double)i * y[i]; }
+    for (int64_t i = 0; i < n; ++i) { const double y = semi(start + i); sy += y; sxy += (double)i * y; }
     const double nn = (double)n;
     const double sx = nn * (nn - 1) / 2;
     const double sxx = (nn - 1) * nn * (2 * nn - 1) / 6;
@@ -44,7 +45,7 @@ Fit fit_run(const double *semi, int64_t start, int64_t end) {
     const double icpt = (sy - slope * sx) / nn;
     double lo = INFINITY, hi = -INFINITY;
     for (int64_t i = 0; i < n; ++i) {
-        const double w = y[i] - (slope * (double)i + icpt);
+        const double w = semi(start + i) - (slope * (double)i + icpt);
         lo = std::min(lo, w); hi = std::max(hi, w);
     }
     const double spread = hi - lo;
@@ -58,16 +59,11 @@ Fit fit_run(const double *semi, int64_t start, int64_t end) {
 }
 
 // get_midi_events (midi_logic.py:32-148) for one clip; returns false when a decision is too close to call
-bool clip_events(const aegis_event_params &P, int64_t F, const uint8_t *sounding, const double *semi_in, const int16_t *bins,
-                 const double *bin_semi, const float *rms_db, const double *probs, int32_t clip, const aegis_run_fit *fits,
-                 int64_t n_fits, std::vector<aegis_event> &out, std::vector<aegis_run_fit> &risky_out) {
-    std::vector<double> semi_tab;
-    const double *semi = semi_in;
-    if (!semi) {                       // hz_to_midi(f0) = hz_to_midi(freqs[bin]): a table lookup
-        semi_tab.resize((size_t)F);
-        for (int64_t i = 0; i < F; ++i) semi_tab[i] = (sounding[i] && bins[i] >= 0) ? bin_semi[bins[i]] : 0.0;
-        semi = semi_tab.data();
-    }
+// semi(i): semitone value of frame i; pitch(i): np.rint of it (half to even) as an integer.
+template <class Semi, class Pitch>
+bool clip_events_t(const aegis_event_params &P, int64_t F, const uint8_t *sounding, const Semi &semi, const Pitch &pitch_of,
+                   const float *rms_db, const double *probs, int32_t clip, const aegis_run_fit *fits,
+                   int64_t n_fits, std::vector<aegis_event> &out, std::vector<aegis_run_fit> &risky_out) {
     const int64_t min_frames = (int64_t)((P.min_note_duration_ms / 1000.0) * P.sample_rate / P.hop_length);
     const int64_t sustain_frames = (int64_t)((P.sustain_ms / 1000.0) * P.sample_rate / P.hop_length);
     std::vector<aegis_event> ev;
@@ -75,9 +71,9 @@ bool clip_events(const aegis_event_params &P, int64_t F, const uint8_t *sounding
     int64_t i = 0;
     while (i < F) {
         if (!sounding[i]) { ++i; continue; }
-        const int64_t pitch = (int64_t)std::nearbyint(semi[i]);          // np.rint: half to even
+        const int64_t pitch = pitch_of(i);
         int64_t j = i + 1;
-        while (j < F && sounding[j] && (int64_t)std::nearbyint(semi[j]) == pitch) ++j;
+        while (j < F && sounding[j] && pitch_of(j) == pitch) ++j;
         const int64_t start = i, end = j - 1;
         i = j;
         if (end - start < min_frames) continue;                         // midi_logic.py:109 (end is inclusive)
@@ -137,6 +133,27 @@ bool clip_events(const aegis_event_params &P, int64_t F, const uint8_t *sounding
     }
     out.insert(out.end(), merged.begin(), merged.end());
     return true;
+}
+
+// get_midi_events for one clip from either form of the pitch track: semitones per frame (semi_in), or the analysis's
+// decoded bins with hz_to_midi(freqs) as a table (no per-frame array is built: the table entry IS the frame's value,
+// and its rounding is looked up instead of computed per frame)
+bool clip_events(const aegis_event_params &P, int64_t F, const uint8_t *sounding, const double *semi_in, const int16_t *bins,
+                 const double *bin_semi, int32_t *bin_pitch, const float *rms_db, const double *probs, int32_t clip,
+                 const aegis_run_fit *fits, int64_t n_fits, std::vector<aegis_event> &out, std::vector<aegis_run_fit> &risky_out) {
+    if (semi_in) {
+        auto semi = [semi_in](int64_t i) { return semi_in[i]; };
+        auto pitch = [semi_in](int64_t i) { return (int64_t)std::nearbyint(semi_in[i]); };
+        return clip_events_t(P, F, sounding, semi, pitch, rms_db, probs, clip, fits, n_fits, out, risky_out);
+    }
+    auto semi = [bins, bin_semi](int64_t i) { return bins[i] >= 0 ? bin_semi[bins[i]] : 0.0; };
+    auto pitch = [bins, bin_semi, bin_pitch](int64_t i) -> int64_t {   // bin_pitch: the worker's lazily filled rint table
+        const int b = bins[i];
+        if (b < 0) return 0;
+        if (bin_pitch[b] == INT32_MIN) bin_pitch[b] = (int32_t)std::nearbyint(bin_semi[b]);
+        return bin_pitch[b];
+    };
+    return clip_events_t(P, F, sounding, semi, pitch, rms_db, probs, clip, fits, n_fits, out, risky_out);
 }
 
 // ---- Standard MIDI File (aegis_engine.py:98-179 through mido: type 1, 480 ticks per beat, running status, end_of_track) ----
@@ -259,12 +276,14 @@ int64_t aegis_extract_events(const aegis_event_params *P, const aegis_event_batc
     std::vector<std::vector<aegis_run_fit>> risky((size_t)n_clips);
     std::atomic<int> next{0};
     auto work = [&]() {
+        std::vector<int32_t> bin_pitch;                                  // rint(bin_semitones[b]) for the bins met (i16 index)
+        if (!B->semitones) bin_pitch.assign(32768, INT32_MIN);
         for (;;) {
             const int c = next.fetch_add(1);
             if (c >= n_clips) break;
             const int64_t a = frame_off[c], F = frame_off[c + 1] - a;
             if (!clip_events(*P, F, B->sounding + a, B->semitones ? B->semitones + a : nullptr, B->pitch_bin ? B->pitch_bin + a : nullptr,
-                             B->bin_semitones, B->rms_db + a, B->probs + a, c, B->fits, B->n_fits, per[c], risky[c]))
+                             B->bin_semitones, bin_pitch.data(), B->rms_db + a, B->probs + a, c, B->fits, B->n_fits, per[c], risky[c]))
                 per[c].clear();
         }
     };

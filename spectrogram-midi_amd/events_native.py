@@ -10,6 +10,8 @@ pull-off tagging, MIDI bytes -- runs in C++ over the clips in parallel.  A clip 
 1e-9 of a threshold is decided by `midi_logic.detect_articulations` (the reference's own np.polyfit arithmetic) for
 that note only, and the batch is run again with those verdicts.  Output: the reference's list-of-dicts schema, identical to the per-clip path."""
 import ctypes as C
+import os
+from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
 
@@ -64,25 +66,79 @@ def _bind():
     return lib
 
 
-def batch_rms_db(rms, frame_off, amin=1e-5, top_db=80.0):
-    """convert.amplitude_to_db_max (librosa.amplitude_to_db(rms, ref=np.max), midi_logic.py:51) for every clip of a
-    concatenated float32 track at once: the same elementwise NumPy kernels on the same values, the per-clip maxima
-    through ufunc.reduceat."""
-    rms = np.asarray(rms)
-    n = len(frame_off) - 1
+def _rms_db_block(rms, frame_off, amin=1e-5, top_db=80.0):
+    """amplitude_to_db(rms, ref=np.max) of every clip of one clip-aligned block (frame_off relative to the block)."""
     counts = np.diff(frame_off)
     live = counts > 0
-    if rms.size == 0:
-        return np.zeros(0, rms.dtype)
     starts = np.asarray(frame_off[:-1])[live]
-    mag = np.abs(rms)
-    peak = np.maximum.reduceat(mag, starts)                      # per live clip
-    db = 10.0 * np.log10(np.maximum(amin ** 2, np.square(mag)))
-    ref = 10.0 * np.log10(np.maximum(amin ** 2, np.square(peak)))
     cl = counts[live]
+    db = np.abs(rms)
+    peak = np.maximum.reduceat(db, starts)                       # per live clip
+    np.square(db, out=db)
+    np.maximum(amin ** 2, db, out=db)
+    np.log10(db, out=db)
+    np.multiply(10.0, db, out=db)
+    ref = 10.0 * np.log10(np.maximum(amin ** 2, np.square(peak)))
     db -= np.repeat(ref, cl)
     floor = np.maximum.reduceat(db, starts) - top_db
-    return np.maximum(db, np.repeat(floor, cl))
+    return np.maximum(db, np.repeat(floor, cl), out=db)
+
+
+_BLOCK_FRAMES = 1 << 17        # half a megabyte of float32 per temporary: stays in the allocator's and the core's cache
+
+
+def _clip_blocks(frame_off, block=_BLOCK_FRAMES):
+    """Cut clips 0..n into runs of whole clips of about `block` frames: [(c0, c1), ...]."""
+    n = len(frame_off) - 1
+    cuts = [0]
+    while cuts[-1] < n:
+        c0 = cuts[-1]
+        c1 = int(np.searchsorted(frame_off, frame_off[c0] + block, side="right")) - 1
+        cuts.append(min(n, max(c1, c0 + 1)))
+    return list(zip(cuts[:-1], cuts[1:]))
+
+
+def _host_workers():
+    try:
+        return max(1, min(16, len(os.sched_getaffinity(0))))
+    except AttributeError:
+        return max(1, min(16, os.cpu_count() or 1))
+
+
+def _map_blocks(fn, blocks):
+    """fn over the blocks on fresh threads, joined before return (NumPy's array kernels release the GIL)."""
+    nw = min(_host_workers(), len(blocks))
+    if nw <= 1:
+        for b in blocks:
+            fn(b)
+        return
+    with ThreadPoolExecutor(max_workers=nw) as pool:
+        for _ in pool.map(fn, blocks):
+            pass
+
+
+def batch_rms_db(rms, frame_off, amin=1e-5, top_db=80.0, gate=None):
+    """convert.amplitude_to_db_max (librosa.amplitude_to_db(rms, ref=np.max), midi_logic.py:51) for every clip of a
+    concatenated float32 track: the same elementwise NumPy kernels on the same values as the per-clip form, the
+    per-clip maxima through ufunc.reduceat -- evaluated over blocks of whole clips (temporaries of half a megabyte
+    instead of one array of the whole folder per operation) on the host threads granted to the process.
+    gate = (out bool array, fn(db block, a, b) -> bool block): a per-frame mask formed from each block while it is hot."""
+    rms = np.asarray(rms)
+    frame_off = np.asarray(frame_off, dtype=np.int64)
+    if rms.size == 0:
+        return np.zeros(0, rms.dtype)
+    out = np.empty(rms.shape, rms.dtype if rms.dtype.kind == "f" else np.float64)
+
+    def one(block):
+        c0, c1 = block
+        a, b = int(frame_off[c0]), int(frame_off[c1])
+        if b > a:
+            out[a:b] = _rms_db_block(rms[a:b], frame_off[c0:c1 + 1] - a, amin, top_db)
+            if gate is not None:
+                gate[0][a:b] = gate[1](out[a:b], a, b)
+
+    _map_blocks(one, _clip_blocks(frame_off))
+    return out
 
 
 def extract_batch(frame_off, rake_mask, f0, voiced_flag, active_probs, rms, sr, hop_length, confidence_threshold=0.70,
@@ -100,15 +156,20 @@ def extract_batch(frame_off, rake_mask, f0, voiced_flag, active_probs, rms, sr, 
     f0 = np.asarray(f0)
     rms = np.asarray(rms)
     probs = np.ascontiguousarray(active_probs, dtype=np.float64)
-    rms_db = np.ascontiguousarray(batch_rms_db(rms, frame_off))
     on_grid = pitch_bin is not None and freqs is not None
+    voiced = np.asarray(voiced_flag, bool)
+    rake = np.asarray(rake_mask, bool)
+    sounding = np.zeros(len(f0), bool)
     if on_grid:        # voiced <=> bin >= 0 <=> f0 = freqs[bin] > 0
         pitch_bin = np.ascontiguousarray(pitch_bin, dtype=np.int16)
-        sounding = np.asarray(voiced_flag, bool) & ~(rms_db < noise_gate_db) & ~np.asarray(rake_mask, bool)
+        gate = lambda db, a, b: voiced[a:b] & ~(db < noise_gate_db) & ~rake[a:b]
+    else:
+        gate = lambda db, a, b: voiced[a:b] & ~(db < noise_gate_db) & (f0[a:b] > 0) & ~rake[a:b]
+    rms_db = batch_rms_db(rms, frame_off, gate=(sounding, gate))
+    if on_grid:
         bin_semi = np.ascontiguousarray(midi_logic.hz_to_midi(np.asarray(freqs, np.float64)))
         semitones = None
     else:
-        sounding = np.asarray(voiced_flag, bool) & ~(rms_db < noise_gate_db) & (f0 > 0) & ~np.asarray(rake_mask, bool)
         semitones = np.zeros(len(f0))
         if sounding.any():
             semitones[sounding] = midi_logic.hz_to_midi(f0[sounding])
