@@ -77,6 +77,27 @@ def folder_durations(n_clips, seed=0):
 
 FOLDER_KINDS = ("guitar",) * 6 + ("polyphonic", "noisy")
 
+# Sum over the folder's 512 clips of crc32(voiced_flag | rake_mask | rms | voiced_prob | f0 with 0 for unvoiced), each seeded
+# with the clip's index: independent of how the clips are sharded over ranks and of every schedule the library may pick.
+# The value below is what tests/test_gpu_engine.py::test_folder_512_clips_one_dense_pass holds its verified outputs to
+# (clips alone, the oracle, both Viterbi builds, both chunk cuts), so a bench line that carries it ran on those outputs.
+FOLDER_DIGEST_EXPECTED = 1136586380622
+
+
+def outputs_digest(host, frame_off, clip_ids):
+    """host: concatenated output arrays of this rank's clips; -> int (sum of per-clip crc32s, < 2**41 for 512 clips)."""
+    import zlib
+    total = 0
+    f0 = np.nan_to_num(host["f0"])
+    for j, cid in enumerate(clip_ids):
+        a, b = int(frame_off[j]), int(frame_off[j + 1])
+        crc = int(cid) & 0xFFFFFFFF
+        for arr in (host["voiced_flag"][a:b].astype(np.uint8), host["rake_mask"][a:b].astype(np.uint8), host["rms"][a:b],
+                    host["voiced_prob"][a:b], f0[a:b]):
+            crc = zlib.crc32(np.ascontiguousarray(arr).tobytes(), crc)
+        total += crc
+    return total
+
 
 def make_folder_clips(indices, durations):
     """The clips `indices` of the folder.  Clip i is cut, at a seeded offset and gain, from one of eight 330 s base
@@ -463,6 +484,7 @@ def main():
                                                pitch_bin=host["pitch_bin"], freqs=handle.table("freqs"))
     local_rows = adist.rows_from_packed(ev_packed, clip_ids)
     events_ms = (time.perf_counter() - t0) * 1e3
+    digest = int(reduce_sum(float(outputs_digest(host, f_off, clip_ids))))    # exact in float64: < 2**41
     gather_ms, n_events = None, int(local_rows.shape[0])
     if world > 1:
         fence()
@@ -577,6 +599,7 @@ def main():
         launches = max(1, kernel_n.get(dom, 0) // max(1, args.steps))
         default_workload = (args.config == "folder" and args.folder_clips == 512 and world == 1) or \
                            (args.config == "shard" and args.clips == 64 and args.clip_seconds == 180.0)
+        default_folder = args.config == "folder" and args.folder_clips == 512       # at any number of ranks: the digest is per clip
         pmc = measured_traffic(dom, args.config) if default_workload else None
         traffic = None if pmc is None else pmc["bytes_per_step"]
         voiced = float(d_out["voiced_flag"].float().mean().item())
@@ -643,6 +666,12 @@ def main():
                          "kernel_ms": {k: round(v, 3) for k, v in kernel_ms.items()}},
             "roofline_compute": roofline_compute,
             "voiced_fraction": round(voiced, 4),
+            # the outputs of the last timed step (all ranks), held to the digest of the outputs the GPU test verified
+            "outputs_check": {"digest": digest,
+                              "expected": FOLDER_DIGEST_EXPECTED if default_folder else None,
+                              "match": (digest == FOLDER_DIGEST_EXPECTED) if (default_folder and FOLDER_DIGEST_EXPECTED is not None) else None,
+                              "what": "sum over clips of crc32(voiced_flag, rake_mask, rms, voiced_prob, f0) seeded with the clip index; "
+                                      "expected = tests/test_gpu_engine.py::test_folder_512_clips_one_dense_pass"},
             "rank_busy_ms": rank_busy_ms, "rank_audio_seconds": rank_audio,
             "events": {"count": n_events, "extract_ms": round(events_ms, 2),
                        "gather_ms": None if gather_ms is None else round(gather_ms, 3),

@@ -84,3 +84,13 @@ def test_folder_mode_two_ranks():
     assert abs(line["config"]["folder_audio_seconds"] - float(np.floor(d * 44100).sum() / 44100)) < 0.1
     assert 0.0 <= line.get("viterbi_list_only_rate", 0.5) <= 1.0
     assert "folder of 6 clips" in line["config"]["workload"] and line["host_inclusive"]["value"] > 0
+    # the two ranks' outputs, digested per clip, are the outputs of the six clips on one handle in one process
+    from spectrogram_midi_amd import _lib
+    clips = bench.make_folder_clips(range(6), d)
+    h = _lib.Handle()
+    res = h.analyze_batch(clips, want_sdb=False)
+    h.close()
+    host = {k: np.concatenate([r[k] for r in res]) for k in ("f0", "voiced_flag", "voiced_prob", "rms", "rake_mask")}
+    f_off = np.concatenate([[0], np.cumsum([len(r["f0"]) for r in res])])
+    assert line["outputs_check"]["digest"] == bench.outputs_digest(host, f_off, range(6))
+    assert line["outputs_check"]["expected"] is None and line["outputs_check"]["match"] is None      # not the 512-clip folder

@@ -70,6 +70,22 @@ def test_sweep_and_empty(eng):
         eng.analyze_array(np.array([0.0, np.nan, 0.1], np.float32))
 
 
+def test_hostile_signals_match_the_oracle(eng):
+    """What a folder of real recordings holds and the synthetic guitar does not (tools/signals.py::hostile_clips: offsets,
+    clipping, impulse trains, levels around the 1e-6 energy clamps of pitch.py, tones outside [fmin, fmax], beating, the
+    Nyquist tone, denormals, a step, white noise): one ragged batch, every raw_data array and the events against the oracle."""
+    clips = signals.hostile_clips()
+    names = list(clips)
+    raws, evs, _ = eng.audio_to_midi_batch([clips[k] for k in names])
+    for k, raw, ev in zip(names, raws, evs):
+        ref = oengine.audio_to_midi(clips[k])
+        assert_raw_equal(raw, ref, k)
+        assert_events_equal(ev, oengine.extract_events(ref), k)
+    solo = eng.analyze_array(clips["clipped"])
+    for key in ("f0", "voiced_flag", "voiced_probs", "rms", "rake_mask"):
+        np.testing.assert_array_equal(solo[key], raws[names.index("clipped")][key], err_msg=key)
+
+
 def test_audio_to_midi_batch_equals_the_per_clip_calls(eng, test_clips):
     """AegisEngine.audio_to_midi_batch: one GPU batch + one batched (C++) event extraction / SMF rendering == the
     reference's two calls per clip, dict for dict and byte for byte; non-finite audio is refused (on the device)."""
@@ -594,6 +610,7 @@ def _check_throughput_pass(monkeypatch, clips, solo, oracle, tag):
         ref = oengine.audio_to_midi(clips[i])
         g = dict(got[i], f0=np.nan_to_num(got[i]["f0"]))
         assert_raw_equal(g, ref, f"{tag}: clip {i} vs oracle")
+    return dev
 
 
 def test_folder_512_clips_one_dense_pass(monkeypatch):
@@ -613,7 +630,10 @@ def test_folder_512_clips_one_dense_pass(monkeypatch):
     solo = sorted({int(order[0]), int(order[-1]), int(poly[len(poly) // 2]), int(noisy[len(noisy) // 2]), 0, 511})
     oracle = [int(order[0]), int(poly[0]), int(noisy[0])]
     assert all(durations[i] <= 60.0 for i in oracle)
-    _check_throughput_pass(monkeypatch, clips, solo, oracle, "folder")
+    dev = _check_throughput_pass(monkeypatch, clips, solo, oracle, "folder")
+    # the digest bench.py prints for its last timed step (`outputs_check`) is the digest of THESE outputs
+    f_off = np.concatenate([[0], np.cumsum([1 + len(c) // 512 for c in clips])])
+    assert bench.FOLDER_DIGEST_EXPECTED is not None and bench.outputs_digest(dev, f_off, range(512)) == bench.FOLDER_DIGEST_EXPECTED
 
 
 def test_256_clips_of_180_s_one_dense_pass(monkeypatch):

@@ -111,3 +111,35 @@ def pitched_start_clip(sr=44100):
     t = np.arange(int(0.8 * sr)) / sr
     return np.concatenate([0.5 * np.sin(2 * np.pi * 880.0 * t), np.zeros(int(0.3 * sr)),
                            0.4 * np.sin(2 * np.pi * 220.0 * t)]).astype(np.float32)
+
+
+def hostile_clips(sr=44100, seconds=2.0):
+    """Signals a folder of real recordings holds and a synthetic guitar does not: offsets, clipping, impulse trains, levels
+    around the difference function's 1e-6 clamps, tones outside [fmin, fmax], beating, the Nyquist tone, float32 denormals,
+    a step.  name -> float32 clip (seeded)."""
+    n = int(seconds * sr)
+    t = np.arange(n) / sr
+    g = guitar_clip(seconds, sr=sr, seed=77)
+    rng = np.random.default_rng(77)
+    imp = np.zeros(n, np.float32)
+    imp[::sr // 110] = 0.9
+    step = np.zeros(n, np.float32)
+    step[n // 2:] = 0.7
+    out = {
+        "dc_offset": g * np.float32(0.5) + np.float32(0.5),
+        "clipped": np.clip(g * np.float32(8.0), -1.0, 1.0),
+        "impulse_train": imp,
+        "quiet_1e-3": g * np.float32(1e-3),
+        "quiet_1e-5": g * np.float32(1e-5),
+        "tone_3k_above_fmax": 0.5 * np.sin(2 * np.pi * 3000.0 * t),
+        "tone_40_below_fmin": 0.5 * np.sin(2 * np.pi * 40.0 * t),
+        "beating_220_223": 0.4 * np.sin(2 * np.pi * 220.0 * t) + 0.4 * np.sin(2 * np.pi * 223.0 * t),
+        "square_100": np.where(np.sin(2 * np.pi * 100.0 * t) >= 0, 1.0, -1.0),
+        "nyquist": 0.9 * np.where(np.arange(n) % 2 == 0, 1.0, -1.0),
+        "denormal": np.full(n, 1e-39),
+        "tremolo_440": 0.5 * np.sin(2 * np.pi * 440.0 * t) * (0.55 + 0.45 * np.sin(2 * np.pi * 8.0 * t)),
+        "white_uniform": rng.uniform(-1.0, 1.0, n),
+        "step": step,
+        "fast_chirp": 0.5 * np.sin(2 * np.pi * (50.0 * t + 0.5 * (4000.0 - 50.0) / seconds * t * t)),
+    }
+    return {k: np.ascontiguousarray(v, dtype=np.float32) for k, v in out.items()}
