@@ -924,7 +924,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                 for (size_t i = ramp.size(); i-- > 1;) { b += ramp[i]; if (b < maxF) cb.push_back(b); }
             } else
             for (int64_t b = 1 + std::max<int64_t>(kViterbiChunk, kTimeChunk - kViterbiChunk); b + kTimeChunk / 2 < maxF; b += kTimeChunk) cb.push_back(b);
-        } else if (py && !tsplit && maxF > kTimeChunk + kTimeChunk / 2) {      // (a time-split pass: the whole frame stage, then all segments at once)
+        } else if (py && tsplit && feed) {
+            // a time-split pass fed from host memory: its segments need every frame's observations, but its frame stage need not
+            // wait for the last sample -- chunks of the feed size, each chunk's copy under the frame stage of the chunk before
+            // (64 x 180 s at 22 050 Hz: copy 20 ms + frame stage 12 ms + segments 22 ms in a row before)
+            const int64_t fc = std::max<int64_t>(4 * kViterbiChunk, h->feed_chunk * 64 / nc / kViterbiChunk * kViterbiChunk);
+            for (int64_t b = 1 + fc - kViterbiChunk; b + fc / 2 < maxF; b += fc) cb.push_back(b);
+        } else if (py && !tsplit && maxF > kTimeChunk + kTimeChunk / 2) {      // (a device-resident time-split pass: the whole frame stage, then all segments at once)
             int64_t step = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
             cb.push_back(1 + step);
             while (cb.back() + kTimeChunk + kTimeChunk / 2 < maxF) {
@@ -983,7 +989,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // ---- streams -----------------------------------------------------------------------------------
         // CU-partitioned streams while the batch leaves compute units free (see split_streams); otherwise the caller's
         // stream carries the frame stage and the handle's second stream the Viterbi.
-        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v) ? split_streams(h, nc) : nullptr;
+        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v && !tsplit) ? split_streams(h, nc) : nullptr;      // (segments want every CU)
         hipStream_t fa = ss ? ss->frame_a : s;
         hipStream_t fb = ss ? ss->frame_b : h->stream4;
         hipStream_t sv = ss ? ss->viterbi : ((py && (nk > 1 || tsplit)) ? h->stream2 : fa);      // (a split pass: the next pass's frame stage runs under its Viterbi kernels)
@@ -991,8 +997,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // streams lets chunk k+1's FFTs overlap chunk k's latency-bound observation kernel.  Small batches are
         // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
         // first four (short) chunks, whose kernels are too small to fill the chip on their own.
-        const bool two_fs = py && nk > 2 && nc >= 128;
-        const int ramp_k = (py && nk > 2 && !two_fs) ? (balanced ? nk : h->ramp_k) : 0;
+        const bool two_fs = py && nk > 2 && nc >= 128 && !tsplit;      // (a chunked split pass keeps one frame stream: its one Viterbi launch waits for the last chunk's event only)
+        const int ramp_k = (py && nk > 2 && !two_fs && !tsplit) ? (balanced ? nk : h->ramp_k) : 0;
         const bool use_fb = two_fs || ramp_k > 0;
         while ((int)h->sync_events.size() < EV_CHUNK0 + nk) {
             hipEvent_t e;
@@ -1186,6 +1192,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     }
                     continue;
                 }
+                if (tsplit && k < nk - 1) continue;      // the segments are launched once, behind the last chunk's observations
                 if (sv != fs) {
                     HIPCHK(h, hipEventRecord(h->sync_events[EV_CHUNK0 + k], fs));
                     HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0 + k], 0));

@@ -795,6 +795,32 @@ def test_time_split_on_one_rank_of_the_folder(monkeypatch):
         np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
 
 
+@pytest.mark.parametrize("sr", [44100, 22050])
+def test_time_split_pass_fed_from_host_memory_chunks_its_frame_stage(sr, monkeypatch):
+    """The host-buffer entry (aegis_analyze_batch) on a pass the planner splits in time: the samples are copied and the frame
+    stage runs chunk by chunk (each copy under the frame stage of the chunk before), the segments are launched once behind
+    the last chunk -- same arrays as the sequential pass and as the device-resident split pass, bit for bit."""
+    clips = [signals.guitar_clip(40.0 + 7 * i, sr=sr, seed=60 + i) if i % 3 else signals.polyphonic_clip(40.0 + 7 * i, sr=sr, seed=60 + i)
+             for i in range(6)]
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    h = _lib.Handle(sample_rate=sr)
+    ref = h.analyze_batch(clips, want_sdb=False)
+    assert h.param("last_split_segments") == 0
+    h.close()
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "512")
+    monkeypatch.setenv("AEGIS_FEED_CHUNK", "96")               # x 64 / 6 clips = 1 024-step chunks
+    h = _lib.Handle(sample_rate=sr)
+    got = h.analyze_batch(clips, want_sdb=False)
+    assert h.param("last_split_segments") >= 12 and h.param("last_chunks") >= 3 and h.param("last_passes") == 1
+    assert h.param("split_flagged_clips") == 0
+    again = h.analyze_batch(clips[::-1], want_sdb=False)[::-1]
+    h.close()
+    for r, g, a in zip(ref, got, again):
+        for k in r:
+            np.testing.assert_array_equal(g[k], r[k], err_msg=k)
+            np.testing.assert_array_equal(a[k], r[k], err_msg=k)
+
+
 def test_out_of_memory_retry_halves_the_passes():
     """An analyze call whose workspace cannot be allocated (another handle or the caller took the memory the pass size was
     derived from) halves max_frames_per_pass -- down to 2^21 frames -- and plans its passes again instead of failing: the first
