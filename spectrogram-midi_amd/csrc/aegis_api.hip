@@ -117,6 +117,16 @@ struct aegis_handle {
     // 86.5 ms against 76.0 as one pass -- the latency-bound parts of a split pass (lock-on tail, rounds of second speculation,
     // verification, exact walk: ~25 ms) do not shrink with half the clips and now run twice.  Off by default.
     int split_sub_passes = 1;
+    // Hybrid split passes (AEGIS_SPLIT_HYBRID: unset = automatic split passes of up to split_limit clips, 1 = forced ones as
+    // well, 0 = never).  A split pass ran its whole frame stage in front of its segments (they need every frame's
+    // observations) with the Viterbi's compute units idle; a hybrid pass runs the balanced pipeline instead -- frame stage on
+    // 192 CUs, the SEQUENTIAL kernel chunk by chunk on 64 -- until the frame stage is through, and cuts only what the
+    // sequential kernel has not reached by then (steps behind hybrid step S of every clip) into speculative segments: the
+    // first segment of every clip is the sequential run itself, as before, only now thousands of steps long and free.
+    // AEGIS_HYBRID_PCT: S as a percentage of (frame stage time on 192 CUs) / (time per step).
+    int split_hybrid = -1, hybrid_pct = 100, hybrid_rounds = 3;      // AEGIS_HYBRID_ROUNDS: rounds of speculative segments behind S
+    int64_t last_hybrid_step = 0;
+    hipEvent_t hyb_ev[3] = {nullptr, nullptr, nullptr};
     bool call_split_started = false;          // this call's first automatic split pass has recorded split_ev[0]
     double call_t_seq = 0.0, call_t_front = 0.0;   // the call's sequential estimate; the first split pass's frame stage (not overlapped)
     int split_bad = 0;                        // automatic split passes in a row that did not pay (two of them start the cool-down)
@@ -344,6 +354,9 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_TROUGHS_IN_FRAME")) h->troughs_off = (e[0] == '0');
     if (const char *e = std::getenv("AEGIS_TIME_SPLIT")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_seglen = v / kViterbiChunk * kViterbiChunk; }
     if (const char *e = std::getenv("AEGIS_SPLIT_SUB_PASSES")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 2) h->split_sub_passes = (int)v; }
+    if (const char *e = std::getenv("AEGIS_SPLIT_HYBRID")) h->split_hybrid = e[0] == '0' ? 0 : 1;
+    if (const char *e = std::getenv("AEGIS_HYBRID_ROUNDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) h->hybrid_rounds = (int)v; }
+    if (const char *e = std::getenv("AEGIS_HYBRID_PCT")) { const long v = std::strtol(e, nullptr, 10); if (v >= 5 && v <= 200) h->hybrid_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_SEGMENT_ROUNDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) h->split_rounds_of_segments = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_WARMUP")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_warmup = (int)(v / kViterbiChunk * kViterbiChunk); }
     if (const char *e = std::getenv("AEGIS_CHUNK_START")) { const long v = std::strtol(e, nullptr, 10); if (v >= 16) h->chunk_start = v; }
@@ -473,6 +486,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     h->events.clear();
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->split_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->hyb_ev) if (e) (void)hipEventDestroy(e);
     T("free tables");
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
@@ -852,8 +866,37 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Viterbi-bound and the gain is the launches and the head (48 clips: 52.0 -> 50.2 ms, 16: 50.2 -> 50.0, 8: 49.5
         // -> 49.8), hence the lower limit; unpartitioned passes lose with small chunks.
         bool split_auto = false;
-        const int64_t seglen = py ? plan_split(pc, nc, fp, maxF, split_auto) : 0;
+        int64_t seglen = py ? plan_split(pc, nc, fp, maxF, split_auto) : 0;
         const bool tsplit = seglen > 0;
+        // hybrid (see split_hybrid): S = the step the sequential kernel reaches while the frame stage runs, on a chunk boundary of
+        // the balanced schedule; worth it when that is at least a couple of segments' worth of steps
+        int64_t hyb_S = 0, hyb_chunk = 0;
+        if (tsplit && !feed && h->split_hybrid != 0 && (split_auto || h->split_hybrid == 1) && nc <= h->split_limit && h->split_limit > 0 &&
+            h->balanced_chunk > 0 && h->n_cus == 256 && split_streams(h, nc) != nullptr) {
+            const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, front = 0.75 * (double)fp * 43e-9 * (256.0 / 192.0);
+            const int64_t target = (int64_t)((double)h->hybrid_pct / 100.0 * front / step);
+            // (one launch of the sequential kernel waiting for a flag per chunk, as in balanced passes: half the chunk size)
+            hyb_chunk = std::max<int64_t>(kViterbiChunk, (h->persistent && sync ? h->balanced_chunk / 2 : h->balanced_chunk) * 64 / nc / kViterbiChunk * kViterbiChunk);
+            const int64_t first = std::max<int64_t>(kViterbiChunk, hyb_chunk - kViterbiChunk);       // chunk 0's steps (balanced schedule below)
+            const int64_t n = target > first ? (target - first + hyb_chunk / 2) / hyb_chunk : 0;
+            const int64_t S0 = first + n * hyb_chunk;
+            if (target >= 2048 && S0 + 4 * kViterbiChunk < maxF - 1) hyb_S = S0;      // (S + 1 is a boundary of the schedule below)
+        }
+        const bool hybrid = hyb_S > 0;
+        if (hybrid && split_auto) {       // the steps left behind S, one round of segments on the whole chip
+            int64_t left = 0;
+            for (int i = 0; i < nc; ++i) left += std::max<int64_t>(0, frames[pc[i]] - 1 - hyb_S);
+            // (whole rounds of workgroups on the 192 compute units the frame stage leaves: the speculative runs start while the
+            // sequential kernel still holds its 64)
+            const int64_t budget = (int64_t)192 * h->hybrid_rounds;
+            seglen = std::max<int64_t>(768, (left / budget + kViterbiChunk) / kViterbiChunk * kViterbiChunk);
+            for (int guard = 0; guard < 64; ++guard) {       // (ceil per clip: lengthen until the segments fit)
+                int64_t ns = 0;
+                for (int i = 0; i < nc; ++i) { const int64_t rest = frames[pc[i]] - 1 - hyb_S; if (rest > 0) ns += (rest + seglen - 1) / seglen; }
+                if (ns <= budget) break;
+                seglen = (seglen + seglen / 32 + kViterbiChunk) / kViterbiChunk * kViterbiChunk;
+            }
+        }
         int n_seg = 0, n_lock = 0, tube_cap = 0;
         if (tsplit) {
             const int L = h->split_warmup;
@@ -861,6 +904,33 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             std::vector<int32_t> sT, sst, sprev, sclip, cseg0(nc + 1, 0);
             for (int i = 0; i < nc; ++i) {
                 const int64_t Fc = frames[pc[i]], steps = Fc - 1;
+                if (hybrid) {
+                    // first segment = the sequential run to step S (a clip that ends by then: all of it, decoded by that kernel, and a
+                    // one-frame placeholder here), then ceil((steps - S) / seglen) segments of equal length behind S
+                    cseg0[i] = n_seg;
+                    const bool more = steps > hyb_S;
+                    sf0.push_back(m.frame_off[i]); sch0.push_back(m.chunk_off[i]);
+                    sT.push_back(more ? (int32_t)(hyb_S + 1) : 1); sst.push_back(0); sprev.push_back(-1); sclip.push_back(i);
+                    ++n_seg;
+                    if (!more) continue;
+                    const int64_t rest = steps - hyb_S;
+                    const int ns = (int)std::max<int64_t>(1, (rest + seglen - 1) / seglen);
+                    int64_t mprev = hyb_S;
+                    for (int k = 0; k < ns; ++k) {
+                        const int64_t mk = k == 0 ? hyb_S : std::max<int64_t>(mprev + kViterbiChunk, hyb_S + (rest * k / ns) / kViterbiChunk * kViterbiChunk);
+                        const int64_t mnext = k == ns - 1 ? Fc - 1 : std::max<int64_t>(mk + kViterbiChunk, hyb_S + (rest * (k + 1) / ns) / kViterbiChunk * kViterbiChunk);
+                        const int64_t wk = std::max<int64_t>(0, mk - L);
+                        sf0.push_back(m.frame_off[i] + wk);
+                        sch0.push_back(m.chunk_off[i] + wk / kViterbiChunk);
+                        sT.push_back((int32_t)(mnext - wk + 1));
+                        sst.push_back((int32_t)(mk - wk));
+                        sprev.push_back(n_seg - 1);
+                        sclip.push_back(i);
+                        mprev = mk;
+                        ++n_seg;
+                    }
+                    continue;
+                }
                 // (ceil: no segment longer than seglen -- the launch lasts as long as its longest segment; with rounding a clip of
                 // 1.49 segment lengths ran as ONE segment and set the pace of the whole launch)
                 const int ns = (int)std::max<int64_t>(1, (steps + seglen - 1) / seglen);
@@ -885,7 +955,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             m.seg64 = sf0; m.seg64.insert(m.seg64.end(), sch0.begin(), sch0.end());
             m.seg32.clear();
             for (auto *v : {&sT, &sst, &sprev, &sclip, &cseg0}) m.seg32.insert(m.seg32.end(), v->begin(), v->end());
-            for (int k = 0; k < n_seg; ++k) m.seg32.push_back(k);                       // seg_order
+            // seg_order: the speculative runs (n_seg entries reserved; a hybrid pass lists only the segments behind the first ones)
+            for (int k = 0; k < n_seg; ++k) if (!hybrid || sprev[k] >= 0) m.seg32.push_back(k);
+            if (hybrid) for (int k = 0; k < n_seg; ++k) if (sprev[k] < 0) m.seg32.push_back(k);       // (padding: keeps the layout)
             for (int k = 0; k < n_seg; ++k) if (sprev[k] >= 0) { m.seg32.push_back(k); ++n_lock; }      // lock_order
         }
         const bool balanced = !tsplit && py && !stream_v && h->balanced_chunk > 0 && nc >= h->balanced_min && h->n_cus == 256 &&
@@ -905,8 +977,17 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             const int64_t at64 = feed ? h->feed_chunk : (may_persist ? h->balanced_chunk / 2 : h->balanced_chunk);
             kTimeChunk = std::max<int64_t>(kViterbiChunk, at64 * 64 / nc / kViterbiChunk * kViterbiChunk);
         }
+        if (hybrid) kTimeChunk = hyb_chunk;       // (the balanced schedule with a Viterbi launch per chunk; S + 1 is one of its boundaries)
         std::vector<int64_t> cb{0};
-        if (balanced && maxF > 2 * kTimeChunk) {
+        if (hybrid) {
+            // chunks of the balanced size while the sequential kernel follows (to step S: the Viterbi sets the pace), then the
+            // rest of the frame stage in a few large ones: a chunk's two kernels take ~0.5 ms however few frames it holds, and
+            // behind S nothing waits for them chunk by chunk (148 chunks of 192 steps: the frame stage alone took 66 ms)
+            const int64_t first = std::max<int64_t>(kViterbiChunk, hyb_chunk - kViterbiChunk);
+            for (int64_t b = 1 + first; b <= hyb_S + 1; b += hyb_chunk) cb.push_back(b);
+            const int64_t big = std::max<int64_t>(hyb_chunk, ((maxF - hyb_S - 1) / 4 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+            for (int64_t b = hyb_S + 1 + big; b + big / 2 < maxF; b += big) cb.push_back(b);
+        } else if (balanced && maxF > 2 * kTimeChunk) {
             // (chunk 0 holds frame 0 besides its steps: one back-pointer block less keeps it inside the round too)
             if (may_persist && h->balanced_ends > 0 && maxF > 8 * kTimeChunk) {
                 // shorter chunks at both ends (the Viterbi starts behind chunk 0 and finishes a chunk after the frame
@@ -954,7 +1035,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         bool proportional = false;
         // (not for a pass fed from host memory: it is bound by the pageable copies, and a short clip's proportional chunk is a
         // copy of a few hundred KB -- 512-clip folder, host-inclusive: 496 ms against 466 on one time axis)
-        if (py && !balanced && !feed && nk > 2 && h->proportional_chunks) {
+        if (py && !balanced && !feed && !tsplit && nk > 2 && h->proportional_chunks) {
             int64_t minF = maxF;
             for (int i = 0; i < nc; ++i) minF = std::min(minF, frames[pc[i]]);
             proportional = 4 * minF < 3 * maxF;
@@ -989,7 +1070,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // ---- streams -----------------------------------------------------------------------------------
         // CU-partitioned streams while the batch leaves compute units free (see split_streams); otherwise the caller's
         // stream carries the frame stage and the handle's second stream the Viterbi.
-        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v && !tsplit) ? split_streams(h, nc) : nullptr;      // (segments want every CU)
+        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v && (!tsplit || hybrid)) ? split_streams(h, nc) : nullptr;      // (segments want every CU)
         hipStream_t fa = ss ? ss->frame_a : s;
         hipStream_t fb = ss ? ss->frame_b : h->stream4;
         hipStream_t sv = ss ? ss->viterbi : ((py && (nk > 1 || tsplit)) ? h->stream2 : fa);      // (a split pass: the next pass's frame stage runs under its Viterbi kernels)
@@ -998,7 +1079,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
         // first four (short) chunks, whose kernels are too small to fill the chip on their own.
         const bool two_fs = py && nk > 2 && nc >= 128 && !tsplit;      // (a chunked split pass keeps one frame stream: its one Viterbi launch waits for the last chunk's event only)
-        const int ramp_k = (py && nk > 2 && !two_fs && !tsplit) ? (balanced ? nk : h->ramp_k) : 0;
+        const int ramp_k = (py && nk > 2 && !two_fs && (!tsplit || hybrid)) ? ((balanced || hybrid) ? nk : h->ramp_k) : 0;
+        // a hybrid pass ends on an unmasked stream: its segments want every CU, the pipeline's Viterbi stream has 64
+        hipStream_t sd = hybrid ? h->stream2 : nullptr;
+        hipStream_t sa = hybrid ? h->stream4 : nullptr;      // its speculative runs: behind the frame stage, beside the sequential kernel's last chunks
         const bool use_fb = two_fs || ramp_k > 0;
         while ((int)h->sync_events.size() < EV_CHUNK0 + nk) {
             hipEvent_t e;
@@ -1007,15 +1091,15 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         }
         auto join_later = [&](hipStream_t q) { if (q != s && std::find(joined.begin(), joined.end(), q) == joined.end()) joined.push_back(q); };
         if (pass_index == 0) HIPCHK(h, hipEventRecord(h->sync_events[EV_START], s));
-        for (hipStream_t q : {fa, fb, sv}) {
-            if (q == s) continue;
+        for (hipStream_t q : {fa, fb, sv, sd, sa}) {
+            if (q == s || q == nullptr) continue;
             if (std::find(joined.begin(), joined.end(), q) == joined.end())
                 HIPCHK(h, hipStreamWaitEvent(q, h->sync_events[EV_START], 0));      // the caller's earlier work on s comes first
             // this workspace was last used two passes ago: everything of that pass must have finished
             if (done_recorded[pass_index & 1]) HIPCHK(h, hipStreamWaitEvent(q, h->sync_events[EV_DONE0 + (pass_index & 1)], 0));
         }
         if (fa == s && done_recorded[pass_index & 1]) HIPCHK(h, hipStreamWaitEvent(s, h->sync_events[EV_DONE0 + (pass_index & 1)], 0));
-        join_later(fa); join_later(sv); if (use_fb) join_later(fb);
+        join_later(fa); join_later(sv); if (use_fb) join_later(fb); if (sd) { join_later(sd); join_later(sa); }
 
         // ---- workspace ---------------------------------------------------------------------------------
         int rc;
@@ -1061,7 +1145,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
         // observation kernel, instead of being launched per chunk (40 launches of 45 us each at 64 clips x 180 s, and the
         // kernel's prologue each time).  It needs the frame stage to run beside it, which the CU partition guarantees.
-        const bool persistent = may_persist && ss != nullptr && nk > 1;
+        const bool persistent = (may_persist || (hybrid && h->persistent && sync)) && ss != nullptr && nk > 1;
         if (persistent) {
             if (!h->abort_flag.p) {
                 if ((rc = ensure(h, h->abort_flag, 4)) != AEGIS_OK) return rc;
@@ -1135,6 +1219,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             p.chunk_flag = static_cast<const uint32_t *>(w.chunk_flag.p);
             p.chunk_lo = static_cast<const int64_t *>(w.chunk_lo.p);
             p.n_chunks = nk;
+            if (hybrid) { int ks = 0; while (ks < nk && cb[ks] <= hyb_S) ++ks; p.n_chunks = ks; }      // (the launch ends at step S: chunks 0 .. ks - 1)
             p.chunk_gen = ++h->chunk_gen;
             if (p.chunk_gen == 0) p.chunk_gen = ++h->chunk_gen;
             p.abort_flag = static_cast<uint32_t *>(h->abort_flag.p);
@@ -1184,7 +1269,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                         HIPCHK(h, hipEventRecord(h->sync_events[EV_CHUNK0], fs));
                         HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0], 0));
                         PassParams pv = p;
-                        pv.vt_begin = 0; pv.vt_end = INT64_MAX;
+                        pv.vt_begin = 0; pv.vt_end = hybrid ? hyb_S + 1 : INT64_MAX;
                         begin_event(h, "viterbi", sv);
                         hipError_t ve = launch_viterbi(pv, h->dt, t.log_trans_band.data(), sv);
                         end_event(h, sv);
@@ -1192,22 +1277,24 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     }
                     continue;
                 }
-                if (tsplit && k < nk - 1) continue;      // the segments are launched once, behind the last chunk's observations
+                if (tsplit && !hybrid && k < nk - 1) continue;      // the segments are launched once, behind the last chunk's observations
+                if (hybrid && chunk_lo(k) > hyb_S) continue;        // (hybrid: behind step S the segments take over, launched after the loop)
                 if (sv != fs) {
                     HIPCHK(h, hipEventRecord(h->sync_events[EV_CHUNK0 + k], fs));
                     HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_CHUNK0 + k], 0));
                 }
                 begin_event(h, "viterbi", sv);
-                if (tsplit && split_auto) {
+                const bool split_now = tsplit && !hybrid;
+                if (split_now && split_auto) {
                     for (auto &e : h->split_ev) if (!e) HIPCHK(h, hipEventCreate(&e));
                     if (!h->call_split_started) { HIPCHK(h, hipEventRecord(h->split_ev[0], sv)); h->call_split_started = true; h->call_t_front = 0.75 * (double)fp * 43e-9; }
                 }
-                hipError_t ve = tsplit ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, d_lock_order, n_lock, sv)
-                                       : launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
-                if (tsplit && split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sv));
+                hipError_t ve = split_now ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, n_seg, d_lock_order, n_lock, sv)
+                                          : launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
+                if (split_now && split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sv));
                 end_event(h, sv);
                 if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
-                if (tsplit) {
+                if (split_now) {
                     h->split_checks.push_back({pass_index & 1, p, nc, split_auto, std::max((double)maxF * (t.half_width == 25 ? 3.1e-6 : 7.3e-6), (double)fp * 43e-9),
                                                0.75 * (double)fp * 43e-9});
                     ++h->split_stats[0]; h->split_stats[1] += n_seg;
@@ -1218,14 +1305,45 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             HIPCHK(h, hipEventRecord(h->sync_events[EV_FB], fb));
             HIPCHK(h, hipStreamWaitEvent(fa, h->sync_events[EV_FB], 0));
         }
-        begin_event(h, "finalize", fa); launch_finalize_mel(p, h->dt, fa); end_event(h, fa);
-        if (py) { begin_event(h, "finalize", sv); launch_decode(p, h->dt, sv); end_event(h, sv); }
-        // pass done = its last kernels on the frame stream and on the Viterbi stream
-        if (sv != fa) {
-            HIPCHK(h, hipEventRecord(h->sync_events[EV_FA], fa));
-            HIPCHK(h, hipStreamWaitEvent(sv, h->sync_events[EV_FA], 0));
+        if (hybrid) {
+            // the segments behind step S: after the last chunk's observations (fa; fb has joined it above) and the sequential
+            // kernel's last launch (sv), on the unmasked stream
+            for (auto &e : h->hyb_ev) if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            PassParams ph = p;
+            ph.split_hybrid = 1; ph.hybrid_step = (int32_t)hyb_S;
+            ph.vt_begin = 0; ph.vt_end = INT64_MAX;
+            // the speculative runs need the observations only: they start behind the frame stage, on the compute units it has
+            // left, while the sequential kernel walks its last chunks; lock-on runs and everything after wait for both
+            HIPCHK(h, hipEventRecord(h->hyb_ev[0], fa));
+            HIPCHK(h, hipStreamWaitEvent(sa, h->hyb_ev[0], 0));
+            hipError_t vs = launch_viterbi_split_spec(ph, h->dt, t.log_trans_band.data(), d_seg_order, n_lock, sa);
+            if (vs != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(vs); return AEGIS_ERR_DEVICE; }
+            HIPCHK(h, hipEventRecord(h->hyb_ev[2], sa));
+            HIPCHK(h, hipEventRecord(h->hyb_ev[1], sv));
+            HIPCHK(h, hipStreamWaitEvent(sd, h->hyb_ev[1], 0));
+            HIPCHK(h, hipStreamWaitEvent(sd, h->hyb_ev[2], 0));
+            begin_event(h, "viterbi", sd);
+            if (split_auto) {
+                for (auto &e : h->split_ev) if (!e) HIPCHK(h, hipEventCreate(&e));
+                if (!h->call_split_started) { HIPCHK(h, hipEventRecord(h->split_ev[0], sd)); h->call_split_started = true; h->call_t_front = (double)fp * 43e-9; }
+            }
+            hipError_t ve = launch_viterbi_split(ph, h->dt, t.log_trans_band.data(), d_seg_order, 0, d_lock_order, n_lock, sd);
+            if (split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sd));
+            end_event(h, sd);
+            if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }
+            h->split_checks.push_back({pass_index & 1, ph, nc, split_auto, std::max((double)maxF * (t.half_width == 25 ? 3.1e-6 : 7.3e-6), (double)fp * 43e-9),
+                                       (double)fp * 43e-9});
+            ++h->split_stats[0]; h->split_stats[1] += n_seg;
         }
-        HIPCHK(h, hipEventRecord(h->sync_events[EV_DONE0 + (pass_index & 1)], sv));
+        hipStream_t se = hybrid ? sd : sv;       // the stream the pass ends on
+        begin_event(h, "finalize", fa); launch_finalize_mel(p, h->dt, fa); end_event(h, fa);
+        if (py) { begin_event(h, "finalize", se); launch_decode(p, h->dt, se); end_event(h, se); }
+        // pass done = its last kernels on the frame stream and on the Viterbi stream
+        if (se != fa) {
+            HIPCHK(h, hipEventRecord(h->sync_events[EV_FA], fa));
+            HIPCHK(h, hipStreamWaitEvent(se, h->sync_events[EV_FA], 0));
+        }
+        HIPCHK(h, hipEventRecord(h->sync_events[EV_DONE0 + (pass_index & 1)], se));
         done_recorded[pass_index & 1] = true;
         HIPCHK(h, hipGetLastError());
         h->last_frames = fp;
@@ -1233,6 +1351,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         h->last_pass_segments = tsplit ? n_seg : 0;
         h->last_chunks = nk; h->last_dense = dense ? 1 : 0; h->last_proportional = proportional ? 1 : 0;
         h->last_balanced = balanced ? 1 : 0; h->last_persistent = persistent ? 1 : 0;
+        h->last_hybrid_step = hyb_S;
         h->last_work = pass_index & 1;
         first = last;
         ++pass_index;
@@ -2104,6 +2223,7 @@ int64_t aegis_get_param(const aegis_handle *h, const char *name) {
     if (n == "last_dense") return h->last_dense;
     if (n == "last_proportional") return h->last_proportional;
     if (n == "last_balanced") return h->last_balanced;
+    if (n == "last_hybrid_step") return h->last_hybrid_step;
     if (n == "last_persistent") return h->last_persistent;
     if (n == "pyin_init") return t.pyin_init;
     return AEGIS_ERR_INVALID;

@@ -111,6 +111,10 @@ struct PassParams {
     uint32_t *clip_flag;         // [n_clips] != 0: the clip's decode could not be certified, the sequential kernel must redo it
     int32_t split_phase;         // 1: speculative runs, 2: lock-on runs
     int32_t n_seg;
+    // Hybrid split pass (aegis_api.hip): the sequential kernel has run every clip's steps 1 .. hybrid_step under the frame
+    // stage (a clip's first segment is that run; vstate holds its last column), only the segments behind it are speculative
+    int32_t split_hybrid;
+    int32_t hybrid_step;
     // workspace (strides in elements)
     double *dfn;   int32_t lag_stride;   // [F][lag_stride]   pyin's difference function d[tau], lags 0..max_period; with
                                          //                   cmnd_in_frame the entries tau >= min_period hold the CMND instead
@@ -152,8 +156,12 @@ void launch_pyin_obs(const PassParams &p, const DevTables &t, hipStream_t s);
 hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double *host_lt_band, hipStream_t s);
 // time-split pass: speculative runs (grid = segments), lock-on runs (grid = segments that have a predecessor, listed in
 // lock_order), stitch + back-trace, verification; seg_order (device) lists 0..n_seg-1
-hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order,
+// (n_spec: entries of seg_order = speculative runs to launch; a hybrid pass lists the segments behind every clip's first only)
+hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
                                 const int32_t *lock_order, int n_lock, hipStream_t s);
+// the speculative runs alone (a hybrid pass launches them behind its frame stage, beside the sequential kernel's last chunks,
+// and the rest -- launch_viterbi_split with n_spec = 0 -- behind both)
+hipError_t launch_viterbi_split_spec(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec, hipStream_t s);
 bool viterbi_split_applies(const PassParams &p, const DevTables &t);
 hipError_t viterbi_verify_fetch(long long *dst, bool reset);
 int viterbi_tube_record_ints();   // counters of the time-split verification kernel (viterbi.hip g_verify_dbg)

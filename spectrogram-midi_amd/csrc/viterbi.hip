@@ -407,10 +407,38 @@ __global__ __launch_bounds__(64) void viterbi_round_kernel(PassParams p, int rou
     p.clip_first[c] = k;
     if (k >= 0) { p.seg_lock[k] = -2; atomicMax(p.tube_count + 1, (uint32_t)(round + 1)); }
 }
+// Hybrid split pass: the sequential kernel ran steps 1 .. hybrid_step of every clip under the frame stage and left its column
+// in vstate.  For a clip that goes on behind that step, the column becomes what a speculative first segment would have
+// left: the segment's end column (lock-on run of the second segment, exact walk), the stored column of the boundary frame
+// with its maximum and arg-max (lowest state on ties, as end_of_step finds it) for the verification kernel.
+__global__ __launch_bounds__(1024) void viterbi_seg0_fill_kernel(PassParams p) {
+    __shared__ double wmax[16];
+    __shared__ int wkg[16];
+    const int c = blockIdx.x, S = 2 * p.n_bins, j = threadIdx.x, lane = j & 63, w = j >> 6;
+    const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
+    if (b - a < 2) return;                       // the sequential kernel finished this clip, back-trace included
+    const int64_t f = p.frame_off[c] + p.hybrid_step;
+    const double v = j < S ? p.vstate[(int64_t)c * S + j] : -INFINITY;
+    if (j < S) { p.seg_col[(int64_t)a * S + j] = v; p.colhist[f * (int64_t)S + j] = v; }
+    double m = v;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = fmax(m, __shfl_xor(m, o));
+    const unsigned long long at = __ballot(j < S && v == m);
+    if (lane == 0) { wmax[w] = m; wkg[w] = at ? w * 64 + (int)__ffsll((long long)at) - 1 : 0x7fffffff; }
+    __syncthreads();
+    if (j == 0) {
+        double G = -INFINITY;
+        int kg = 0x7fffffff;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k)
+            if (wmax[k] > G || (wmax[k] == G && wkg[k] < kg)) { G = wmax[k]; kg = wkg[k]; }
+        p.colG[f] = G; p.colkg[f] = kg; p.seg_kg[a] = kg;
+    }
+}
 __global__ __launch_bounds__(64) void viterbi_stitch_kernel(PassParams p) {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= p.n_clips) return;
     const int S = 2 * p.n_bins, a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
+    if (p.split_hybrid && b - a < 2) return;     // (hybrid pass: decoded by the sequential kernel already)
     bool bad = false;
     for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] == -1;      // (-2: a later round started over from its end column)
     int e = p.seg_kg[b - 1];
@@ -1009,7 +1037,7 @@ bool viterbi_split_applies(const PassParams &p, const DevTables &t) {
     return viterbi_band_applies(p, t) && p.width <= 128;
 }
 template <int H>
-static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order,
+static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
                                        const int32_t *lock_order, int n_lock, hipStream_t s) {
     const int BP = (p.n_bins + 63) & ~63;
     BandLT<H> blt;
@@ -1021,7 +1049,8 @@ static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, 
     const size_t lds = viterbi_band_lds<H>(p, true) + 64 * 8;     // + the lock-on comparison's per-wave extremes
     PassParams q = p;
     q.split_phase = 1; q.order = seg_order;
-    hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)p.n_seg), dim3(2 * BP), lds, s, q, t, blt);
+    if (n_spec > 0) hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_spec), dim3(2 * BP), lds, s, q, t, blt);
+    if (n_lock < 0) return hipGetLastError();       // (speculative runs only: launch_viterbi_split_spec)
     if (n_lock > 0) {
         q.split_phase = 2; q.order = lock_order;
         hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
@@ -1043,11 +1072,17 @@ hipError_t viterbi_verify_fetch(long long *dst, bool reset) {
     if (e == hipSuccess && reset) { static long long z[16]; e = hipMemcpyToSymbol(HIP_SYMBOL(g_verify_dbg), z, sizeof(z)); }
     return e;
 }
-hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order,
+hipError_t launch_viterbi_split_spec(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec, hipStream_t s) {
+    if (n_spec <= 0) return hipSuccess;
+    return p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, n_spec, nullptr, -1, s)
+                              : launch_split_kernels<50>(p, t, host_lt_band, seg_order, n_spec, nullptr, -1, s);
+}
+hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
                                 const int32_t *lock_order, int n_lock, hipStream_t s) {
     if (p.n_seg == 0) return hipSuccess;
-    hipError_t e = p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, lock_order, n_lock, s)
-                                      : launch_split_kernels<50>(p, t, host_lt_band, seg_order, lock_order, n_lock, s);
+    if (p.split_hybrid) hipLaunchKernelGGL(viterbi_seg0_fill_kernel, dim3((unsigned)p.n_clips), dim3(1024), 0, s, p);
+    hipError_t e = p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, n_spec, lock_order, n_lock, s)
+                                      : launch_split_kernels<50>(p, t, host_lt_band, seg_order, n_spec, lock_order, n_lock, s);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(viterbi_segmap_kernel, dim3((unsigned)p.n_seg), dim3(1024), 0, s, p);
     hipLaunchKernelGGL(viterbi_stitch_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, p);

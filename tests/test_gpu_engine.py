@@ -821,6 +821,42 @@ def test_time_split_pass_fed_from_host_memory_chunks_its_frame_stage(sr, monkeyp
             np.testing.assert_array_equal(a[k], r[k], err_msg=k)
 
 
+@pytest.mark.parametrize("persistent", ["1", "0"])
+def test_hybrid_split_pass_equals_the_sequential_run(persistent, monkeypatch):
+    """A split pass of <= 64 clips as the planner runs it on a rank's shard of the folder (aegis_api.hip split_hybrid): the
+    balanced pipeline -- frame stage on 192 CUs, the sequential kernel on 64 -- until the frame stage is through, and only
+    the steps behind the step S the sequential kernel has reached by then cut into speculative segments.  48 ragged clips
+    (tonal, polyphonic, noisy, one shorter than S, one silent): every output array equal to the sequential pass's."""
+    rng = np.random.default_rng(21)
+    base = [signals.guitar_clip(150.0, seed=71), signals.polyphonic_clip(150.0, seed=72), signals.guitar_clip(150.0, seed=73, noise_dbfs=-12.0)]
+    clips = []
+    for i in range(48):
+        n = int(rng.uniform(20.0, 150.0) * 44100)
+        a = int(rng.integers(0, len(base[0]) - n + 1))
+        clips.append(np.ascontiguousarray(base[i % 3][a:a + n]))
+    clips[5] = clips[5][:44100 * 8]                          # ends long before S
+    clips[6] = np.zeros(44100 * 100, np.float32)             # unvoiced throughout: rails
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    h = _lib.Handle()
+    ref = _analyze_on_device(h, clips)
+    h.close()
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "640")
+    monkeypatch.setenv("AEGIS_SPLIT_HYBRID", "1")
+    monkeypatch.setenv("AEGIS_VITERBI_PERSISTENT", persistent)
+    h = _lib.Handle()
+    got = _analyze_on_device(h, clips)
+    S = h.param("last_hybrid_step")
+    assert 2048 <= S < max(len(c) for c in clips) // 512 and h.param("last_split_segments") > 48 + 20
+    assert h.param("last_persistent") == int(persistent) and int(h.debug_fetch("persistent_fallbacks")[0]) == 0
+    assert h.param("split_flagged_clips") <= 1
+    assert sum(1 for c in clips if len(c) // 512 <= S) >= 3              # clips the sequential kernel finished on its own
+    again = _analyze_on_device(h, clips)
+    h.close()
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+        np.testing.assert_array_equal(again[k], ref[k], err_msg=k)
+
+
 def test_out_of_memory_retry_halves_the_passes():
     """An analyze call whose workspace cannot be allocated (another handle or the caller took the memory the pass size was
     derived from) halves max_frames_per_pass -- down to 2^21 frames -- and plans its passes again instead of failing: the first

@@ -28,11 +28,16 @@ def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", FORCE))
             "rake_mask": torch.empty(F, dtype=torch.uint8, device=dev)}
     ptrs = {k: v.data_ptr() for k, v in outs.items()}
     res, ref = {}, None
-    for name, env in modes:
+    for mode in modes:
+        name, env = mode[0], mode[1]
+        extra = mode[2] if len(mode) > 2 else {}
         if env is None:
             os.environ.pop("AEGIS_TIME_SPLIT", None)
         else:
             os.environ["AEGIS_TIME_SPLIT"] = env
+        for k in ("AEGIS_SPLIT_HYBRID", "AEGIS_HYBRID_PCT", "AEGIS_HYBRID_ROUNDS"):
+            os.environ.pop(k, None)
+        os.environ.update(extra)
         h = _lib.Handle()
         h.set_profiling(True)
         ts = []
@@ -48,7 +53,8 @@ def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", FORCE))
         same = all(np.array_equal(got[k], ref[k], equal_nan=True) for k in got)
         res[name] = {"ms": round(ms, 3), "audio_s_per_s": round(float(n.sum()) / 44100 / (ms * 1e-3), 1),
                      "kernel_ms": {k: round(h.kernel_ms(k), 3) for k in ("frame", "pyin_obs", "viterbi", "finalize")},
-                     "segments": h.param("last_split_segments"), "calls": reps + 1,
+                     "segments": h.param("last_split_segments"), "hybrid_step": h.param("last_hybrid_step"), "calls": reps + 1,
+                     "all_ms": [round(x * 1e3, 2) for x in ts[1:]],
                      "clips_redone_sequentially": h.param("split_flagged_clips"), "of_which_never_locked": h.param("split_unlocked_clips"),
                      "outputs_equal_sequential": bool(same),
                      "verify": dict(zip(("frames", "tubes_opened", "tubes_recorded", "too_wide", "-", "closed_elsewhere", "open_at_exact_run", "too_deep", "max_depth", "oob_in_bound", "last_column_tie", "records_full", "tubes_resolved", "path_changed", "tubes_with_rail", "rail_frames"), (int(x) for x in h.debug_fetch("split_verify")[:16])))}
@@ -72,6 +78,18 @@ if "rank8" in which:
     durations = bench.folder_durations(512)
     mine = adist.shard_clips(durations, 8)[0]
     run(bench.make_folder_clips(mine, durations), "rank 0 of 8: its 64 clips of the 512-clip folder", kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
+HYB = (("sequential", "0"), ("split, frame stage in front", FORCE, {"AEGIS_SPLIT_HYBRID": "0"}), ("hybrid", FORCE)) + tuple(
+    (f"hybrid {pct} % / {r} round(s)", FORCE, {"AEGIS_HYBRID_PCT": str(pct), "AEGIS_HYBRID_ROUNDS": str(r)})
+    for pct, r in ((85, 1), (95, 1), (105, 1), (85, 2), (95, 2), (105, 2), (95, 3), (105, 3), (115, 3)))
+if "rank8h" in which:           # the hybrid split pass (aegis_api.hip split_hybrid) on rank 0's shard
+    durations = bench.folder_durations(512)
+    mine = adist.shard_clips(durations, 8)[0]
+    run(bench.make_folder_clips(mine, durations), "rank 0 of 8, hybrid split pass", reps=6, modes=HYB, kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
+if "ranksh" in which:
+    durations = bench.folder_durations(512)
+    shards = adist.shard_clips(durations, 8)
+    for r in range(8):
+        run(bench.make_folder_clips(shards[r], durations), f"rank {r} of 8", reps=8, modes=(HYB[0], HYB[1], HYB[2]), kinds=[bench.FOLDER_KINDS[i % 8] for i in shards[r]])
 if "rank8tonal" in which:       # rank 0's shard with the noisy eighth of the folder replaced by tonal clips: what the split does when every clip locks on
     durations = bench.folder_durations(512)
     mine = adist.shard_clips(durations, 8)[0]
