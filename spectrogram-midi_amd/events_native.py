@@ -17,6 +17,11 @@ import numpy as np
 
 from . import _lib, midi_logic, smf
 
+try:        # csrc/pyevents.c, built by csrc/Makefile next to libaegis_hip.so
+    from . import _aegis_pyevents as _pyevents
+except ImportError:
+    _pyevents = None
+
 TECH = (None, "vibrato", "bend", "slide", "hammer_on", "pull_off")
 _TECH_CODE = {t: i for i, t in enumerate(TECH)}
 
@@ -231,6 +236,10 @@ def extract_batch(frame_off, rake_mask, f0, voiced_flag, active_probs, rms, sr, 
     # ---- the reference's list of dicts ------------------------------------------------------------------------------
     conf = events["confidence"]                         # np.float64 / np.float32 scalars, as the reference's events carry
     energy = events["rms_energy"]
+    if _pyevents is not None:       # the same dicts (same keys in the same order, same value types), built in C
+        rows = _pyevents.event_dicts(np.ascontiguousarray(events), list(conf), list(energy), TECH)
+        per_clip = [rows[ev_off[c]:ev_off[c + 1]] for c in range(n)]
+        return (per_clip, blobs) if want_midi else per_clip
     rows = [{"note": a, "start": b, "end": c, "confidence": d, "velocity": e, "track": "main" if f else "safe",
              "rms_energy": g, "technique": TECH[h], "slope": i}
             for a, b, c, d, e, f, g, h, i in zip(events["note"].tolist(), events["start"].tolist(), events["end"].tolist(),
