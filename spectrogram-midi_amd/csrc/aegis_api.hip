@@ -124,7 +124,7 @@ struct aegis_handle {
     // sequential kernel has not reached by then (steps behind hybrid step S of every clip) into speculative segments: the
     // first segment of every clip is the sequential run itself, as before, only now thousands of steps long and free.
     // AEGIS_HYBRID_PCT: S as a percentage of (frame stage time on 192 CUs) / (time per step).
-    int split_hybrid = -1, hybrid_pct = 100, hybrid_rounds = 3;      // AEGIS_HYBRID_ROUNDS: rounds of speculative segments behind S
+    int split_hybrid = -1, hybrid_pct = 100, hybrid_rounds = 3, hybrid_min_seg = 768;      // AEGIS_HYBRID_ROUNDS: rounds of speculative segments behind S
     int64_t last_hybrid_step = 0;
     hipEvent_t hyb_ev[3] = {nullptr, nullptr, nullptr};
     bool call_split_started = false;          // this call's first automatic split pass has recorded split_ev[0]
@@ -356,6 +356,7 @@ int aegis_create(const aegis_config *cfg, aegis_handle **out) {
     if (const char *e = std::getenv("AEGIS_SPLIT_SUB_PASSES")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 2) h->split_sub_passes = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_HYBRID")) h->split_hybrid = e[0] == '0' ? 0 : 1;
     if (const char *e = std::getenv("AEGIS_HYBRID_ROUNDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) h->hybrid_rounds = (int)v; }
+    if (const char *e = std::getenv("AEGIS_HYBRID_MIN_SEG")) { const long v = std::strtol(e, nullptr, 10); if (v >= 64 && v <= 65536) h->hybrid_min_seg = (int)(v / kViterbiChunk * kViterbiChunk); }
     if (const char *e = std::getenv("AEGIS_HYBRID_PCT")) { const long v = std::strtol(e, nullptr, 10); if (v >= 5 && v <= 200) h->hybrid_pct = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_SEGMENT_ROUNDS")) { const long v = std::strtol(e, nullptr, 10); if (v >= 1 && v <= 8) h->split_rounds_of_segments = (int)v; }
     if (const char *e = std::getenv("AEGIS_SPLIT_WARMUP")) { const long v = std::strtol(e, nullptr, 10); if (v >= 0) h->split_warmup = (int)(v / kViterbiChunk * kViterbiChunk); }
@@ -889,7 +890,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             // (whole rounds of workgroups on the 192 compute units the frame stage leaves: the speculative runs start while the
             // sequential kernel still holds its 64)
             const int64_t budget = (int64_t)192 * h->hybrid_rounds;
-            seglen = std::max<int64_t>(768, (left / budget + kViterbiChunk) / kViterbiChunk * kViterbiChunk);
+            seglen = std::max<int64_t>(h->hybrid_min_seg, (left / budget + kViterbiChunk) / kViterbiChunk * kViterbiChunk);
             for (int guard = 0; guard < 64; ++guard) {       // (ceil per clip: lengthen until the segments fit)
                 int64_t ns = 0;
                 for (int i = 0; i < nc; ++i) { const int64_t rest = frames[pc[i]] - 1 - hyb_S; if (rest > 0) ns += (rest + seglen - 1) / seglen; }

@@ -128,3 +128,25 @@ def test_table_lookup_of_the_pitch_grid_gives_the_same_events(golden):
     assert a[1] == b[1] and sum(len(e) for e in a[0]) > 40
     for x, y in zip(a[0], b[0]):
         assert_same(x, y, "grid")
+
+
+def test_event_dicts_built_in_c_are_the_comprehensions(golden, monkeypatch):
+    """csrc/pyevents.c (_aegis_pyevents.event_dicts) against the Python comprehension it replaces in extract_batch: equal
+    dicts, keys in the same order, values of the same types (np.float64 confidence, np.float32 rms_energy, int, str / None)."""
+    assert en._pyevents is not None, "csrc/Makefile builds _aegis_pyevents.so next to libaegis_hip.so"
+    arrays, meta = golden
+    clips = list(meta["events"])
+    raws = [{k: arrays[f"{c}/{k}"] for k in KEYS} for c in clips] + [{k: arrays[f"fuzz{i}/{k}"] for k in KEYS} for i in range(len(meta["fuzz"]))]
+    n = [min(len(r["rake_mask"]), len(r["f0"]), len(r["rms"])) for r in raws]
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    cat = {k: np.concatenate([r[k][:m] for r, m in zip(raws, n)]) for k in KEYS}
+    run = lambda: en.extract_batch(off, cat["rake_mask"], cat["f0"], cat["voiced_flag"], cat["voiced_probs"], cat["rms"], 44100, 512, 0.70)
+    fast = run()
+    monkeypatch.setattr(en, "_pyevents", None)
+    slow = run()
+    assert sum(len(c) for c in fast) > 100 and fast == slow
+    for a, b in zip(fast, slow):
+        for x, y in zip(a, b):
+            assert list(x) == list(y) and [type(v) for v in x.values()] == [type(v) for v in y.values()]
+    techs = {e["technique"] for c in fast for e in c}
+    assert None in techs and len(techs) >= 4

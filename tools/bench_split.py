@@ -35,7 +35,7 @@ def run(clips, label, reps=5, modes=(("sequential", "0"), ("time-split", FORCE))
             os.environ.pop("AEGIS_TIME_SPLIT", None)
         else:
             os.environ["AEGIS_TIME_SPLIT"] = env
-        for k in ("AEGIS_SPLIT_HYBRID", "AEGIS_HYBRID_PCT", "AEGIS_HYBRID_ROUNDS"):
+        for k in ("AEGIS_SPLIT_HYBRID", "AEGIS_HYBRID_PCT", "AEGIS_HYBRID_ROUNDS", "AEGIS_HYBRID_MIN_SEG"):
             os.environ.pop(k, None)
         os.environ.update(extra)
         h = _lib.Handle()
@@ -79,8 +79,8 @@ if "rank8" in which:
     mine = adist.shard_clips(durations, 8)[0]
     run(bench.make_folder_clips(mine, durations), "rank 0 of 8: its 64 clips of the 512-clip folder", kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
 HYB = (("sequential", "0"), ("split, frame stage in front", FORCE, {"AEGIS_SPLIT_HYBRID": "0"}), ("hybrid", FORCE)) + tuple(
-    (f"hybrid {pct} % / {r} round(s)", FORCE, {"AEGIS_HYBRID_PCT": str(pct), "AEGIS_HYBRID_ROUNDS": str(r)})
-    for pct, r in ((85, 1), (95, 1), (105, 1), (85, 2), (95, 2), (105, 2), (95, 3), (105, 3), (115, 3)))
+    (f"hybrid {pct} % / {r} round(s) / min {ms}", FORCE, {"AEGIS_HYBRID_PCT": str(pct), "AEGIS_HYBRID_ROUNDS": str(r), "AEGIS_HYBRID_MIN_SEG": str(ms)})
+    for pct, r, ms in ((100, 3, 768), (100, 4, 512), (100, 5, 512), (100, 6, 384), (108, 4, 512), (92, 4, 512)))
 if "rank8h" in which:           # the hybrid split pass (aegis_api.hip split_hybrid) on rank 0's shard
     durations = bench.folder_durations(512)
     mine = adist.shard_clips(durations, 8)[0]
