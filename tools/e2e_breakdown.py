@@ -8,7 +8,7 @@ import bench
 from spectrogram_midi_amd import events_native as en
 from spectrogram_midi_amd.engine import AegisEngine
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 512
 dur = bench.folder_durations(n)
 clips = bench.make_folder_clips(list(range(n)), dur)
 audio = float(sum(len(c) for c in clips)) / bench.SR
@@ -49,6 +49,15 @@ for it in range(4):
     T["events"] = sum(len(e) for e in evs)
     del raws, evs, blobs
     rows.append({k: round(v, 2) for k, v in T.items()})
+if "--profile" in sys.argv:
+    import cProfile, pstats
+    raws, bufs, off, live = eng.analyze_arrays(clips, _concatenated=True)
+    pr = cProfile.Profile()
+    pr.enable()
+    en_extract(off, bufs["rake_mask"], bufs["f0"], bufs["voiced_flag"], bufs["voiced_prob"], bufs["rms"], eng.sr, eng.hop_length, 0.70,
+               want_midi=True, pitch_bin=bufs["pitch_bin"], freqs=eng.handle.table("freqs"))
+    pr.disable()
+    pstats.Stats(pr, stream=sys.stderr).sort_stats("tottime").print_stats(14)
 best = min(rows[1:], key=lambda r: r["audio_to_midi_batch"])
 print(json.dumps({"clips": n, "audio_s": round(audio, 1), "host_workers": en._host_workers(), "runs": rows,
                   "audio_s_per_s": round(audio / (best["audio_to_midi_batch"] / 1e3), 1)}, indent=1))
