@@ -321,8 +321,9 @@ int aegis_set_table(aegis_handle *h, const char *name, const double *data, int64
  * "last_chunks", "last_dense", "last_proportional", "last_balanced", "last_persistent", "last_split_segments"; since create:
  * "split_passes", "split_segments", "split_flagged_clips" (clips the sequential kernel decoded again), "split_unlocked_clips";
  * of the last split pass: "split_rounds" (rounds of second speculation that had work), "split_viterbi_us" (measured time of its Viterbi
- * kernels, automatic passes only), "split_cooldown" (calls left that plan sequentially after split passes that did not pay)
- * -- the time-split Viterbi, csrc/viterbi.hip. */
+ * kernels, automatic passes only), "split_cooldown" (calls left that plan sequentially after split passes that did not pay),
+ * "last_hybrid_step" (the step up to which the sequential kernel ran every clip under the frame stage before the rest was
+ * cut into segments; 0: not a hybrid split pass) -- the time-split Viterbi, csrc/viterbi.hip. */
 int64_t aegis_get_param(const aegis_handle *h, const char *name);
 
 /* Copies an intermediate of the most recent pass (device -> host), for stage-level
