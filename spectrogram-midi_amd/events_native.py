@@ -205,11 +205,16 @@ def extract_batch(frame_off, rake_mask, f0, voiced_flag, active_probs, rms, sr, 
             if fits is not None:
                 raise RuntimeError("native event extraction did not accept the supplied verdicts")
             fits = risky[:n_risky.value].copy()
+            seen = {}       # the verdict is a function of the run's f0 values alone, and tracks on a pitch grid repeat their runs
             for r in fits:
                 a = int(frame_off[r["clip"]])
-                tech, slope = midi_logic.detect_articulations(f0[a:int(frame_off[r["clip"] + 1])], int(r["start"]), int(r["end"]),
-                                                              sr, hop_length)
-                r["technique"], r["slope"] = _TECH_CODE[tech], slope
+                run = f0[a + int(r["start"]):a + int(r["end"]) + 1]
+                key = run.tobytes()
+                hit = seen.get(key)
+                if hit is None:
+                    tech, slope = midi_logic.detect_articulations(run, 0, len(run) - 1, sr, hop_length)
+                    hit = seen[key] = (_TECH_CODE[tech], slope)
+                r["technique"], r["slope"] = hit
             batch.fits, batch.n_fits = fits.ctypes.data, len(fits)
             continue
         if total <= cap:

@@ -857,6 +857,47 @@ def test_hybrid_split_pass_equals_the_sequential_run(persistent, monkeypatch):
         np.testing.assert_array_equal(again[k], ref[k], err_msg=k)
 
 
+def test_hybrid_split_pass_at_22050_hz(monkeypatch):
+    """The same at the v2 engine's rate (H = 50 band kernel, 7.3 us per step): a device-resident batch of 64 clips is where the
+    planner takes a hybrid pass there.  Device entry of a 22 050 Hz handle, 64 ragged clips of 60 .. 180 s."""
+    import torch
+    sr = 22050
+    rng = np.random.default_rng(22)
+    base = [signals.guitar_clip(180.0, sr=sr, seed=81), signals.polyphonic_clip(180.0, sr=sr, seed=82), signals.guitar_clip(180.0, sr=sr, seed=83, noise_dbfs=-12.0)]
+    clips = []
+    for i in range(64):
+        n = int(rng.uniform(60.0, 180.0) * sr)
+        a = int(rng.integers(0, len(base[0]) - n + 1))
+        clips.append(np.ascontiguousarray(base[i % 3][a:a + n]))
+    dev = torch.device("cuda", 0)
+    n = np.array([len(c) for c in clips], np.int64)
+    off = np.concatenate([[0], np.cumsum(n)]).astype(np.int64)
+    F = int(sum(1 + len(c) // 512 for c in clips))
+    d_pcm = torch.from_numpy(np.concatenate(clips)).to(dev)
+
+    def run(h):
+        outs = {"f0": torch.empty(F, dtype=torch.float64, device=dev), "voiced_flag": torch.empty(F, dtype=torch.uint8, device=dev),
+                "voiced_prob": torch.empty(F, dtype=torch.float64, device=dev), "rms": torch.empty(F, dtype=torch.float32, device=dev),
+                "rake_mask": torch.empty(F, dtype=torch.uint8, device=dev)}
+        h.analyze_batch_device(d_pcm.data_ptr(), off, {k: v.data_ptr() for k, v in outs.items()}, sync=True)
+        return {k: v.cpu().numpy() for k, v in outs.items()}
+
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    h = _lib.Handle(sample_rate=sr)
+    ref = run(h)
+    h.close()
+    monkeypatch.delenv("AEGIS_TIME_SPLIT")
+    monkeypatch.setenv("AEGIS_HYBRID_PCT", "130")
+    h = _lib.Handle(sample_rate=sr)
+    got = run(h)                                             # the automatic rule
+    S = h.param("last_hybrid_step")
+    assert S >= 2048 and h.param("last_split_segments") > 64 and h.param("split_flagged_clips") <= 1
+    assert int(h.debug_fetch("persistent_fallbacks")[0]) == 0
+    h.close()
+    for k in ref:
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+
+
 def test_out_of_memory_retry_halves_the_passes():
     """An analyze call whose workspace cannot be allocated (another handle or the caller took the memory the pass size was
     derived from) halves max_frames_per_pass -- down to 2^21 frames -- and plans its passes again instead of failing: the first
