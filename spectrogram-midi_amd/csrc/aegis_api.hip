@@ -774,8 +774,10 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
     const bool split_ok = py && !stream_v && sync && h->split_seglen != 0 && viterbi_split_applies(base_params(t), h->dt);
     bool split_cooling = false;
     if (split_ok && h->split_seglen < 0 && h->split_cooldown > 0) { --h->split_cooldown; split_cooling = true; }
+    const bool feed_pass = feed != nullptr;
+    bool want_hybrid = false;      // set by plan_split: the pass pays only in the hybrid form (no split pass if that cannot be set up)
     auto plan_split = [&](const int *clips_of_pass, int nc, int64_t fp, int64_t maxF, bool &automatic) -> int64_t {
-        automatic = false;
+        automatic = false; want_hybrid = false;
         if (!split_ok || nc >= 256) return 0;
         if (h->split_seglen > 0) return h->split_seglen;
         if (split_cooling) return 0;
@@ -795,6 +797,19 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         const double t_seq = std::max((double)maxF * step, work);
         const double t_split = 0.75 * work + (double)(sl + h->split_warmup + 600) * step + 2.5e-3;
         if (t_split < 0.8 * t_seq) { automatic = true; return sl; }
+        // Passes of 65 .. 255 clips that the rule above leaves alone: too much work for a frame stage IN FRONT of the segments
+        // to pay, but their frame stage is through long before their longest clip (128 ragged clips, a rank of four: frame stage
+        // 71 ms, last Viterbi launch 118 ms -- one in eight compute units busy in between).  The hybrid form costs no front:
+        // the sequential launches run under the frame stage as they do today (5.2 us per step beside it, measured), and what the
+        // longest clip has left when the frame stage ends is cut into segments.  Estimate: frame stage, then one segment +
+        // warm-up per round and 12 ms of lock-on runs, verification and exact walk -- against the frame stage plus the steps
+        // the longest clip still has to walk alone.
+        if (h->split_hybrid != 0 && nc > h->split_limit && !feed_pass) {
+            const double front = 0.8 * work, s_est = front / (1.7 * step);
+            const double t_seq2 = std::max(t_seq, front + std::max(0.0, (double)maxF - s_est) * step);
+            const double t_hyb = front + (double)h->hybrid_rounds * (double)(h->hybrid_min_seg + h->split_warmup) * 1.1 * step + 12e-3;
+            if ((double)maxF > s_est + 4096 && t_hyb < 0.9 * t_seq2) { automatic = true; want_hybrid = true; return h->hybrid_min_seg; }
+        }
         return 0;
     };
     // Sub-passes.  A split pass runs its frame stage IN FRONT of its segments (they need every frame's observations), and
@@ -868,28 +883,59 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // -> 49.8), hence the lower limit; unpartitioned passes lose with small chunks.
         bool split_auto = false;
         int64_t seglen = py ? plan_split(pc, nc, fp, maxF, split_auto) : 0;
-        const bool tsplit = seglen > 0;
+        bool tsplit = seglen > 0;
         // hybrid (see split_hybrid): S = the step the sequential kernel reaches while the frame stage runs, on a chunk boundary of
-        // the balanced schedule; worth it when that is at least a couple of segments' worth of steps
+        // the schedule the pass would take anyway -- up to split_limit clips the balanced one on the CU-partitioned streams (ONE
+        // launch of the sequential kernel), above it the ramp of growing chunks on the un-partitioned streams (a launch per
+        // chunk, 5.2 us per step beside the frame stage); worth it when S is at least a couple of segments' worth of steps.
+        // hyb_cb: the pass's chunk boundaries, S + 1 among them; behind S four large chunks (nothing waits for them one by one).
         int64_t hyb_S = 0, hyb_chunk = 0;
-        if (tsplit && !feed && h->split_hybrid != 0 && (split_auto || h->split_hybrid == 1) && nc <= h->split_limit && h->split_limit > 0 &&
-            h->balanced_chunk > 0 && h->n_cus == 256 && split_streams(h, nc) != nullptr) {
-            const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6, front = 0.75 * (double)fp * 43e-9 * (256.0 / 192.0);
-            const int64_t target = (int64_t)((double)h->hybrid_pct / 100.0 * front / step);
-            // (one launch of the sequential kernel waiting for a flag per chunk, as in balanced passes: half the chunk size)
-            hyb_chunk = std::max<int64_t>(kViterbiChunk, (h->persistent && sync ? h->balanced_chunk / 2 : h->balanced_chunk) * 64 / nc / kViterbiChunk * kViterbiChunk);
-            const int64_t first = std::max<int64_t>(kViterbiChunk, hyb_chunk - kViterbiChunk);       // chunk 0's steps (balanced schedule below)
-            const int64_t n = target > first ? (target - first + hyb_chunk / 2) / hyb_chunk : 0;
-            const int64_t S0 = first + n * hyb_chunk;
-            if (target >= 2048 && S0 + 4 * kViterbiChunk < maxF - 1) hyb_S = S0;      // (S + 1 is a boundary of the schedule below)
+        bool hyb_part = false;
+        std::vector<int64_t> hyb_cb;
+        if (tsplit && !feed && h->split_hybrid != 0 && (split_auto || h->split_hybrid == 1) && h->n_cus == 256) {
+            const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6;
+            hyb_part = nc <= h->split_limit && h->split_limit > 0 && h->balanced_chunk > 0 && split_streams(h, nc) != nullptr;
+            const double front = hyb_part ? 0.75 * (double)fp * 43e-9 * (256.0 / 192.0) : 0.8 * (double)fp * 43e-9;
+            const int64_t target = (int64_t)((double)h->hybrid_pct / 100.0 * front / (hyb_part ? step : 1.7 * step));
+            std::vector<int64_t> bs{0};
+            if (hyb_part) {
+                // (one launch of the sequential kernel waiting for a flag per chunk, as in balanced passes: half the chunk size)
+                hyb_chunk = std::max<int64_t>(kViterbiChunk, (h->persistent && sync ? h->balanced_chunk / 2 : h->balanced_chunk) * 64 / nc / kViterbiChunk * kViterbiChunk);
+                for (int64_t b = 1 + std::max<int64_t>(kViterbiChunk, hyb_chunk - kViterbiChunk); b < maxF; b += hyb_chunk) bs.push_back(b);
+            } else {
+                int64_t stp = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
+                for (int64_t b = 1 + stp; b < maxF;) {
+                    bs.push_back(b);
+                    stp = std::min<int64_t>(h->time_chunk, (stp * h->chunk_growth_pct / 100 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                    b += stp;
+                }
+            }
+            size_t best = 0;       // the boundary nearest the target
+            for (size_t i = 1; i < bs.size(); ++i)
+                if (std::llabs(bs[i] - 1 - target) < std::llabs(bs[best] - 1 - target)) best = i;
+            const int64_t S0 = best > 0 ? bs[best] - 1 : 0;
+            if (target >= 2048 && S0 >= 1024 && S0 + 4 * kViterbiChunk < maxF - 1) {
+                hyb_S = S0;
+                if (hyb_part) {
+                    hyb_cb.assign(bs.begin(), bs.begin() + (long)best + 1);
+                    const int64_t big = std::max<int64_t>(4 * kViterbiChunk, ((maxF - hyb_S - 1) / 4 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
+                    for (int64_t b = hyb_S + 1 + big; b + big / 2 < maxF; b += big) hyb_cb.push_back(b);
+                } else {
+                    // (un-partitioned: the sequential launches share the compute units with the frame stage, and four large chunks
+                    // queued in front of them held them back -- at step 7.8 k instead of 13.4 k when the frame stage was through)
+                    hyb_cb = bs;
+                    while (hyb_cb.size() > 1 && hyb_cb.back() + h->time_chunk / 2 >= maxF && hyb_cb.back() > hyb_S + 1) hyb_cb.pop_back();
+                }
+            }
         }
+        if (want_hybrid && hyb_S == 0) { seglen = 0; split_auto = false; tsplit = false; }      // (planned for the hybrid form only)
         const bool hybrid = hyb_S > 0;
         if (hybrid && split_auto) {       // the steps left behind S, one round of segments on the whole chip
             int64_t left = 0;
             for (int i = 0; i < nc; ++i) left += std::max<int64_t>(0, frames[pc[i]] - 1 - hyb_S);
             // (whole rounds of workgroups on the 192 compute units the frame stage leaves: the speculative runs start while the
             // sequential kernel still holds its 64)
-            const int64_t budget = (int64_t)192 * h->hybrid_rounds;
+            const int64_t budget = (int64_t)(hyb_part ? 192 : h->n_cus) * h->hybrid_rounds;
             seglen = std::max<int64_t>(h->hybrid_min_seg, (left / budget + kViterbiChunk) / kViterbiChunk * kViterbiChunk);
             for (int guard = 0; guard < 64; ++guard) {       // (ceil per clip: lengthen until the segments fit)
                 int64_t ns = 0;
@@ -978,16 +1024,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             const int64_t at64 = feed ? h->feed_chunk : (may_persist ? h->balanced_chunk / 2 : h->balanced_chunk);
             kTimeChunk = std::max<int64_t>(kViterbiChunk, at64 * 64 / nc / kViterbiChunk * kViterbiChunk);
         }
-        if (hybrid) kTimeChunk = hyb_chunk;       // (the balanced schedule with a Viterbi launch per chunk; S + 1 is one of its boundaries)
+        if (hybrid && hyb_part) kTimeChunk = hyb_chunk;
         std::vector<int64_t> cb{0};
         if (hybrid) {
-            // chunks of the balanced size while the sequential kernel follows (to step S: the Viterbi sets the pace), then the
+            // chunks of the schedule's own size while the sequential kernel follows (to step S: the Viterbi sets the pace), then the
             // rest of the frame stage in a few large ones: a chunk's two kernels take ~0.5 ms however few frames it holds, and
             // behind S nothing waits for them chunk by chunk (148 chunks of 192 steps: the frame stage alone took 66 ms)
-            const int64_t first = std::max<int64_t>(kViterbiChunk, hyb_chunk - kViterbiChunk);
-            for (int64_t b = 1 + first; b <= hyb_S + 1; b += hyb_chunk) cb.push_back(b);
-            const int64_t big = std::max<int64_t>(hyb_chunk, ((maxF - hyb_S - 1) / 4 + kViterbiChunk - 1) / kViterbiChunk * kViterbiChunk);
-            for (int64_t b = hyb_S + 1 + big; b + big / 2 < maxF; b += big) cb.push_back(b);
+            cb = hyb_cb;
         } else if (balanced && maxF > 2 * kTimeChunk) {
             // (chunk 0 holds frame 0 besides its steps: one back-pointer block less keeps it inside the round too)
             if (may_persist && h->balanced_ends > 0 && maxF > 8 * kTimeChunk) {
@@ -1071,7 +1114,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // ---- streams -----------------------------------------------------------------------------------
         // CU-partitioned streams while the batch leaves compute units free (see split_streams); otherwise the caller's
         // stream carries the frame stage and the handle's second stream the Viterbi.
-        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v && (!tsplit || hybrid)) ? split_streams(h, nc) : nullptr;      // (segments want every CU)
+        aegis_handle::SplitSet *ss = (py && nk > 1 && !stream_v && (!tsplit || (hybrid && hyb_part))) ? split_streams(h, nc) : nullptr;      // (segments want every CU)
         hipStream_t fa = ss ? ss->frame_a : s;
         hipStream_t fb = ss ? ss->frame_b : h->stream4;
         hipStream_t sv = ss ? ss->viterbi : ((py && (nk > 1 || tsplit)) ? h->stream2 : fa);      // (a split pass: the next pass's frame stage runs under its Viterbi kernels)
@@ -1079,11 +1122,13 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // streams lets chunk k+1's FFTs overlap chunk k's latency-bound observation kernel.  Small batches are
         // Viterbi-bound and want each chunk's frame stage finished as early as possible: one stream, except for the
         // first four (short) chunks, whose kernels are too small to fill the chip on their own.
-        const bool two_fs = py && nk > 2 && nc >= 128 && !tsplit;      // (a chunked split pass keeps one frame stream: its one Viterbi launch waits for the last chunk's event only)
-        const int ramp_k = (py && nk > 2 && !two_fs && (!tsplit || hybrid)) ? ((balanced || hybrid) ? nk : h->ramp_k) : 0;
-        // a hybrid pass ends on an unmasked stream: its segments want every CU, the pipeline's Viterbi stream has 64
+        const bool two_fs = py && nk > 2 && nc >= 128 && (!tsplit || hybrid);      // (a chunked split pass fed from host memory keeps one frame stream: its one Viterbi launch waits for the last chunk's event only)
+        const int ramp_k = (py && nk > 2 && !two_fs && (!tsplit || hybrid)) ? ((balanced || (hybrid && hyb_part)) ? nk : h->ramp_k) : 0;
+        // a hybrid pass ends on an unmasked stream (its segments want every CU, the partitioned pipeline's Viterbi stream has 64);
+        // its speculative runs go behind the frame stage, beside the sequential kernel's last chunks: a stream of their own on
+        // the partitioned set, the frame stream itself otherwise
         hipStream_t sd = hybrid ? h->stream2 : nullptr;
-        hipStream_t sa = hybrid ? h->stream4 : nullptr;      // its speculative runs: behind the frame stage, beside the sequential kernel's last chunks
+        hipStream_t sa = hybrid ? (hyb_part ? h->stream4 : fa) : nullptr;
         const bool use_fb = two_fs || ramp_k > 0;
         while ((int)h->sync_events.size() < EV_CHUNK0 + nk) {
             hipEvent_t e;
@@ -1315,18 +1360,31 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             ph.vt_begin = 0; ph.vt_end = INT64_MAX;
             // the speculative runs need the observations only: they start behind the frame stage, on the compute units it has
             // left, while the sequential kernel walks its last chunks; lock-on runs and everything after wait for both
-            HIPCHK(h, hipEventRecord(h->hyb_ev[0], fa));
-            HIPCHK(h, hipStreamWaitEvent(sa, h->hyb_ev[0], 0));
+            if (sa != fa) {
+                HIPCHK(h, hipEventRecord(h->hyb_ev[0], fa));
+                HIPCHK(h, hipStreamWaitEvent(sa, h->hyb_ev[0], 0));
+            }
             hipError_t vs = launch_viterbi_split_spec(ph, h->dt, t.log_trans_band.data(), d_seg_order, n_lock, sa);
             if (vs != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(vs); return AEGIS_ERR_DEVICE; }
             HIPCHK(h, hipEventRecord(h->hyb_ev[2], sa));
-            HIPCHK(h, hipEventRecord(h->hyb_ev[1], sv));
-            HIPCHK(h, hipStreamWaitEvent(sd, h->hyb_ev[1], 0));
+            if (sd != sv) {
+                HIPCHK(h, hipEventRecord(h->hyb_ev[1], sv));
+                HIPCHK(h, hipStreamWaitEvent(sd, h->hyb_ev[1], 0));
+            }
             HIPCHK(h, hipStreamWaitEvent(sd, h->hyb_ev[2], 0));
             begin_event(h, "viterbi", sd);
             if (split_auto) {
                 for (auto &e : h->split_ev) if (!e) HIPCHK(h, hipEventCreate(&e));
-                if (!h->call_split_started) { HIPCHK(h, hipEventRecord(h->split_ev[0], sd)); h->call_split_started = true; h->call_t_front = (double)fp * 43e-9; }
+                if (!h->call_split_started) {
+                    HIPCHK(h, hipEventRecord(h->split_ev[0], sd)); h->call_split_started = true;
+                    // what precedes the events: the frame stage on 192 CUs / beside 65 .. 255 Viterbi workgroups; and for a pass
+                    // planned in the hybrid form only, the sequential estimate that rule used (frame stage + the longest clip's rest)
+                    h->call_t_front = hyb_part ? (double)fp * 43e-9 : 0.8 * (double)fp * 43e-9;
+                    if (want_hybrid) {
+                        const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6;
+                        h->call_t_seq = std::max(h->call_t_seq, h->call_t_front + std::max(0.0, (double)maxF - h->call_t_front / (1.7 * step)) * step);
+                    }
+                }
             }
             hipError_t ve = launch_viterbi_split(ph, h->dt, t.log_trans_band.data(), d_seg_order, 0, d_lock_order, n_lock, sd);
             if (split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sd));

@@ -90,6 +90,13 @@ if "ranksh" in which:
     shards = adist.shard_clips(durations, 8)
     for r in range(8):
         run(bench.make_folder_clips(shards[r], durations), f"rank {r} of 8", reps=8, modes=(HYB[0], HYB[1], HYB[2]), kinds=[bench.FOLDER_KINDS[i % 8] for i in shards[r]])
+if "rank4h" in which:           # a rank of FOUR: 128 ragged clips, un-partitioned streams -- the planner's hybrid-only rule
+    durations = bench.folder_durations(512)
+    shards = adist.shard_clips(durations, 4)
+    for r in (int(x) for x in os.environ.get("BENCH_SPLIT_RANKS", "0,3").split(",")):
+        run(bench.make_folder_clips(shards[r], durations), f"rank {r} of 4", reps=6,
+            modes=(("sequential", "0"), ("automatic (hybrid)", None), ("hybrid 85 %", None, {"AEGIS_HYBRID_PCT": "85"}), ("hybrid 115 %", None, {"AEGIS_HYBRID_PCT": "115"})),
+            kinds=[bench.FOLDER_KINDS[i % 8] for i in shards[r]])
 if "rank8tonal" in which:       # rank 0's shard with the noisy eighth of the folder replaced by tonal clips: what the split does when every clip locks on
     durations = bench.folder_durations(512)
     mine = adist.shard_clips(durations, 8)[0]

@@ -1,9 +1,9 @@
 #!/bin/bash
 # kernel timeline of the last call of tools/split_probe.py (rank shard $1) under rocprofv3 --kernel-trace -> gpurun_out/$2
-R=${1:-0}; OUT=${2:-split_timeline.txt}
+R=${1:-0}; OUT=${2:-split_timeline.txt}; W=${3:-8}
 O=$GRAFT_REPO_ROOT/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp; rm -rf /tmp/p_tl
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tl -o tl -- python3 $GRAFT_REPO_ROOT/tools/split_probe.py $R > $O/$OUT.log 2>&1; echo "trace rc=$?"
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d /tmp/p_tl -o tl -- python3 $GRAFT_REPO_ROOT/tools/split_probe.py $R $W > $O/$OUT.log 2>&1; echo "trace rc=$?"
 F=$(find /tmp/p_tl -name "*kernel_trace.csv" | head -1)
 python3 - "$F" > $O/$OUT <<'PY'
 import csv, sys
