@@ -857,6 +857,40 @@ def test_hybrid_split_pass_equals_the_sequential_run(persistent, monkeypatch):
         np.testing.assert_array_equal(again[k], ref[k], err_msg=k)
 
 
+def test_hybrid_split_pass_of_more_than_64_clips(monkeypatch):
+    """The hybrid form on the UN-partitioned streams (a pass of 65 .. 255 clips: what a rank of four holds): the ramp's chunks
+    with a launch of the sequential kernel per chunk up to step S, the speculative runs on the frame stream behind its last
+    kernel.  72 ragged clips; forced segments, and the planner's own second rule on a batch it applies to."""
+    rng = np.random.default_rng(23)
+    base = [signals.guitar_clip(200.0, seed=91), signals.polyphonic_clip(200.0, seed=92), signals.guitar_clip(200.0, seed=93, noise_dbfs=-12.0)]
+    clips = []
+    for i in range(72):
+        n = int(rng.uniform(20.0, 200.0) * 44100)
+        a = int(rng.integers(0, len(base[0]) - n + 1))
+        clips.append(np.ascontiguousarray(base[i % 3][a:a + n]))
+    monkeypatch.setenv("AEGIS_TIME_SPLIT", "0")
+    h = _lib.Handle()
+    ref = _analyze_on_device(h, clips)
+    h.close()
+    for env in ({"AEGIS_TIME_SPLIT": "640", "AEGIS_SPLIT_HYBRID": "1"}, {}):
+        monkeypatch.delenv("AEGIS_TIME_SPLIT", raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        h = _lib.Handle()
+        got = _analyze_on_device(h, clips)
+        S = h.param("last_hybrid_step")
+        if env:
+            assert S >= 2048 and h.param("last_split_segments") > 72 + 50 and h.param("last_balanced") == 0 and h.param("last_persistent") == 0
+        assert h.param("split_flagged_clips") <= 1
+        auto_segments = h.param("last_split_segments")
+        h.close()
+        for k in ref:
+            np.testing.assert_array_equal(got[k], ref[k], err_msg=f"{k} {env}")
+        for k in env:
+            monkeypatch.delenv(k)
+    assert auto_segments >= 0          # (whether the second rule takes this batch depends on its longest clip; either way the outputs are the sequential pass's)
+
+
 def test_hybrid_split_pass_at_22050_hz(monkeypatch):
     """The same at the v2 engine's rate (H = 50 band kernel, 7.3 us per step): a device-resident batch of 64 clips is where the
     planner takes a hybrid pass there.  Device entry of a 22 050 Hz handle, 64 ragged clips of 60 .. 180 s."""
