@@ -127,6 +127,7 @@ struct aegis_handle {
     int split_hybrid = -1, hybrid_pct = 100, hybrid_rounds = 3, hybrid_min_seg = 768;      // AEGIS_HYBRID_ROUNDS: rounds of speculative segments behind S
     int64_t last_hybrid_step = 0;
     hipEvent_t hyb_ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t fin_ev[2] = {nullptr, nullptr};       // fork / join of a split pass's two finishing streams (launch_viterbi_split)
     bool call_split_started = false;          // this call's first automatic split pass has recorded split_ev[0]
     double call_t_seq = 0.0, call_t_front = 0.0;   // the call's sequential estimate; the first split pass's frame stage (not overlapped)
     int split_bad = 0;                        // automatic split passes in a row that did not pay (two of them start the cool-down)
@@ -488,6 +489,7 @@ static void destroy_now(aegis_handle *h) noexcept {
     for (hipEvent_t e : h->sync_events) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->split_ev) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->hyb_ev) if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->fin_ev) if (e) (void)hipEventDestroy(e);
     T("free tables");
     for (void *p : h->table_allocs) (void)hipFree(p);
     if (h->cqt_bank.dev) (void)hipFree(h->cqt_bank.dev);
@@ -1161,7 +1163,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             if (proportional) ENS(clip_tb, (size_t)(nk + 1) * nc * 8);
             if (tsplit) {
                 ENS(seg64, m.seg64.size() * 8); ENS(seg32, m.seg32.size() * 4);
-                ENS(seg_col, (size_t)2 * n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, ((size_t)n_seg * 3 + nc) * 4);
+                ENS(seg_col, (size_t)2 * n_seg * S * 8); ENS(seg_map, (size_t)n_seg * S * 2); ENS(seg_i32, ((size_t)n_seg * 3 + 2 * nc) * 4);
                 ENS(colhist, (size_t)fp * S * 8); ENS(colG, (size_t)fp * 8); ENS(colkg, (size_t)fp * 4); ENS(clip_flag, (size_t)nc * 4);
                 ENS(flag_order, (size_t)nc * 4);
                 tube_cap = (int)std::max<int64_t>(4096, fp / 128);
@@ -1182,7 +1184,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         if (tsplit) {
             HIPCHK(h, hipMemcpyAsync(w.seg64.p, m.seg64.data(), m.seg64.size() * 8, hipMemcpyHostToDevice, fa));
             HIPCHK(h, hipMemcpyAsync(w.seg32.p, m.seg32.data(), m.seg32.size() * 4, hipMemcpyHostToDevice, fa));
-            HIPCHK(h, hipMemsetAsync(w.seg_i32.p, 0, ((size_t)n_seg * 3 + nc) * 4, fa));       // seg_lock = 0 for the segments without a lock-on run
+            HIPCHK(h, hipMemsetAsync(w.seg_i32.p, 0, ((size_t)n_seg * 3 + 2 * nc) * 4, fa));       // seg_lock = 0 for the segments without a lock-on run
             HIPCHK(h, hipMemsetAsync(w.clip_flag.p, 0, (size_t)nc * 4, fa));
             HIPCHK(h, hipMemsetAsync(w.tube_at.p, 0, (size_t)fp * 4, fa));
             HIPCHK(h, hipMemsetAsync(w.tube_count.p, 0, 8, fa));       // tubes recorded, rounds of second speculation that had work
@@ -1253,7 +1255,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             d_seg_order = g32 + 4 * n_seg + nc + 1; d_lock_order = d_seg_order + n_seg;
             p.seg_col = static_cast<double *>(w.seg_col.p); p.seg_col2 = p.seg_col + (size_t)n_seg * S;
             p.seg_map = static_cast<uint16_t *>(w.seg_map.p);
-            p.seg_kg = static_cast<int32_t *>(w.seg_i32.p); p.seg_lock = p.seg_kg + n_seg; p.seg_end = p.seg_kg + 2 * n_seg; p.clip_first = p.seg_kg + 3 * n_seg;
+            p.seg_kg = static_cast<int32_t *>(w.seg_i32.p); p.seg_lock = p.seg_kg + n_seg; p.seg_end = p.seg_kg + 2 * n_seg; p.clip_first = p.seg_kg + 3 * n_seg; p.clip_dirty = p.clip_first + nc;
             p.colhist = static_cast<double *>(w.colhist.p); p.colG = static_cast<double *>(w.colG.p); p.colkg = static_cast<int32_t *>(w.colkg.p);
             p.clip_flag = static_cast<uint32_t *>(w.clip_flag.p);
             p.tube_buf = static_cast<int32_t *>(w.tube_buf.p); p.tube_cap = tube_cap; p.tube_count = static_cast<uint32_t *>(w.tube_count.p);
@@ -1335,7 +1337,9 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     for (auto &e : h->split_ev) if (!e) HIPCHK(h, hipEventCreate(&e));
                     if (!h->call_split_started) { HIPCHK(h, hipEventRecord(h->split_ev[0], sv)); h->call_split_started = true; h->call_t_front = 0.75 * (double)fp * 43e-9; }
                 }
-                hipError_t ve = split_now ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, n_seg, d_lock_order, n_lock, sv)
+                if (split_now) for (auto &e : h->fin_ev) if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                hipError_t ve = split_now ? launch_viterbi_split(p, h->dt, t.log_trans_band.data(), d_seg_order, n_seg, d_lock_order, n_lock, sv,
+                                                                 h->stream4 != sv ? h->stream4 : nullptr, h->fin_ev)
                                           : launch_viterbi(p, h->dt, t.log_trans_band.data(), sv);
                 if (split_now && split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sv));
                 end_event(h, sv);
@@ -1386,7 +1390,8 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     }
                 }
             }
-            hipError_t ve = launch_viterbi_split(ph, h->dt, t.log_trans_band.data(), d_seg_order, 0, d_lock_order, n_lock, sd);
+            for (auto &e : h->fin_ev) if (!e) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            hipError_t ve = launch_viterbi_split(ph, h->dt, t.log_trans_band.data(), d_seg_order, 0, d_lock_order, n_lock, sd, h->stream4, h->fin_ev);
             if (split_auto) HIPCHK(h, hipEventRecord(h->split_ev[1], sd));
             end_event(h, sd);
             if (ve != hipSuccess) { h->err = std::string("viterbi launch: ") + hipGetErrorString(ve); return AEGIS_ERR_DEVICE; }

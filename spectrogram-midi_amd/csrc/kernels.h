@@ -100,6 +100,8 @@ struct PassParams {
     double *seg_col;             // [n_seg][2 n_bins] end column of the speculative run
     double *seg_col2;            // [n_seg][2 n_bins] end column of a lock-on run that never met the speculative one (the next round speculates from it)
     int32_t *clip_first;         // [n_clips] the clip's first segment whose lock-on run never met (this round; -1: none)
+    int32_t *clip_dirty;         // [n_clips] != 0: a lock-on run of the clip never met (set by the first round): its stitch / verification / exact walk wait for the rounds
+    int32_t clip_sel;            // stitch .. exact walk kernels: 0 every clip, 1 only the clips with clip_dirty == 0, 2 only the others
     int32_t *seg_kg;             // [n_seg] its arg-max
     int32_t *seg_lock;           // [n_seg] local step at which the lock-on run met the speculative run, -1: it did not, -2: it did not and a later round started over from its end column
     int32_t *seg_end;            // [n_seg] decoded state at the segment's last frame (stitch)
@@ -157,8 +159,10 @@ hipError_t launch_viterbi(const PassParams &p, const DevTables &t, const double 
 // time-split pass: speculative runs (grid = segments), lock-on runs (grid = segments that have a predecessor, listed in
 // lock_order), stitch + back-trace, verification; seg_order (device) lists 0..n_seg-1
 // (n_spec: entries of seg_order = speculative runs to launch; a hybrid pass lists the segments behind every clip's first only)
+// (aux + ev[2]: when given, the clips without a never-met lock-on run are stitched, verified and walked on `aux` while the
+// rounds of second speculation of the others run on `s`; `s` has joined `aux` when the call returns)
 hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
-                                const int32_t *lock_order, int n_lock, hipStream_t s);
+                                const int32_t *lock_order, int n_lock, hipStream_t s, hipStream_t aux = nullptr, hipEvent_t *ev = nullptr);
 // the speculative runs alone (a hybrid pass launches them behind its frame stage, beside the sequential kernel's last chunks,
 // and the rest -- launch_viterbi_split with n_spec = 0 -- behind both)
 hipError_t launch_viterbi_split_spec(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec, hipStream_t s);

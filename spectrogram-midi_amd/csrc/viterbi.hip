@@ -8,6 +8,7 @@
 // together (64 clips x 180 s: 69.2 -> 61.4 ms with the merging off).
 //
 // Built with -ffp-contract=off: every add below rounds exactly where NumPy rounds.
+#include <functional>
 #include "kernels.h"
 
 #include <algorithm>
@@ -385,10 +386,15 @@ __global__ __launch_bounds__(1024) void viterbi_band_split_kernel(PassParams p, 
 //      is in play) is flagged and redone by the sequential kernel.
 // Outputs are therefore those of the sequential kernel by construction, not by luck.
 // ------------------------------------------------------------------------------------------
+// clip_sel (PassParams): the stitch .. exact-walk kernels of a pass run once for the clips whose lock-on runs all met
+// (beside the rounds of second speculation of the others) and once for the others, behind their rounds
+__device__ __forceinline__ bool clip_selected(const PassParams &p, int c) {
+    return p.clip_sel == 0 || ((p.clip_dirty[c] != 0) == (p.clip_sel == 2));
+}
 __global__ __launch_bounds__(1024) void viterbi_segmap_kernel(PassParams p) {
     constexpr int C = kViterbiChunk;
     const int sg = blockIdx.x, S = 2 * p.n_bins, j = threadIdx.x;
-    if (j >= S) return;
+    if (j >= S || !clip_selected(p, p.seg_clip[sg])) return;
     const int T = p.seg_T[sg], st = p.seg_store[sg];
     const uint16_t *__restrict__ cmap = p.cmap + p.seg_ch0[sg] * S;
     int s = j;
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(64) void viterbi_round_kernel(PassParams p, int rou
     for (int sg = p.clip_seg0[c] + 1; sg < p.clip_seg0[c + 1]; ++sg)
         if (p.seg_lock[sg] == -1) { k = sg; break; }
     p.clip_first[c] = k;
+    if (round == 0) p.clip_dirty[c] = k >= 0 ? 1 : 0;
     if (k >= 0) { p.seg_lock[k] = -2; atomicMax(p.tube_count + 1, (uint32_t)(round + 1)); }
 }
 // Hybrid split pass: the sequential kernel ran steps 1 .. hybrid_step of every clip under the frame stage and left its column
@@ -439,6 +446,7 @@ __global__ __launch_bounds__(64) void viterbi_stitch_kernel(PassParams p) {
     if (c >= p.n_clips) return;
     const int S = 2 * p.n_bins, a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
     if (p.split_hybrid && b - a < 2) return;     // (hybrid pass: decoded by the sequential kernel already)
+    if (!clip_selected(p, c)) return;
     bool bad = false;
     for (int k = a + 1; k < b; ++k) bad |= p.seg_lock[k] == -1;      // (-2: a later round started over from its end column)
     int e = p.seg_kg[b - 1];
@@ -450,7 +458,7 @@ __global__ __launch_bounds__(256) void viterbi_segtrace_kernel(PassParams p) {
     constexpr int C = kViterbiChunk;
     const int sg = blockIdx.x, S = 2 * p.n_bins, tid = threadIdx.x;
     const int T = p.seg_T[sg], st = p.seg_store[sg];
-    if (T - 1 <= st) return;
+    if (T - 1 <= st || !clip_selected(p, p.seg_clip[sg])) return;
     const int64_t f0 = p.seg_f0[sg], ch0 = p.seg_ch0[sg];
     const uint16_t *__restrict__ cmap = p.cmap + ch0 * S;
     const uint16_t *__restrict__ ptr = p.ptr + f0 * S;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.frame_off[mid] <= f) lo = mid; else hi = mid; }
     const int c = lo;
     const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
-    if (b - a < 2) return;                                        // an unsplit clip is the sequential run itself
+    if (b - a < 2 || !clip_selected(p, c)) return;                // an unsplit clip is the sequential run itself
     const int64_t fc = p.frame_off[c];
     const int64_t fx = p.seg_f0[a + 1] + p.seg_store[a + 1];      // the first boundary: everything up to it is the exact run
     if (f <= fx) return;
@@ -731,7 +739,7 @@ __global__ __launch_bounds__(64) void viterbi_exact_kernel(PassParams p, DevTabl
     const int c = blockIdx.x, lane = threadIdx.x;
     const int B = p.n_bins, S = 2 * B, H = p.half_width;
     const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
-    if (b - a < 2) return;
+    if (b - a < 2 || !clip_selected(p, c)) return;
     if (__hip_atomic_load(&p.clip_flag[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;     // the sequential kernel redoes it anyway
     const int64_t fc = p.frame_off[c], fx = p.seg_f0[a + 1] + p.seg_store[a + 1];
     const int64_t fend = fc + (p.frame_off[c + 1] - fc) - 1;
@@ -1038,7 +1046,7 @@ bool viterbi_split_applies(const PassParams &p, const DevTables &t) {
 }
 template <int H>
 static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
-                                       const int32_t *lock_order, int n_lock, hipStream_t s) {
+                                       const int32_t *lock_order, int n_lock, hipStream_t s, const std::function<void()> &fork = nullptr) {
     const int BP = (p.n_bins + 63) & ~63;
     BandLT<H> blt;
     for (int q = 0; q < 4; ++q) {
@@ -1058,6 +1066,7 @@ static hipError_t launch_split_kernels(const PassParams &p, const DevTables &t, 
         // clips without one return at once.  What is still unmet after the last round flags its clip (stitch kernel).
         for (int round = 0; round < kSplitRounds; ++round) {
             hipLaunchKernelGGL(viterbi_round_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, q, round);
+            if (round == 0 && fork) fork();       // (clip_dirty is known: the clean clips' stitch .. exact walk start beside the rounds)
             q.split_phase = 3;
             hipLaunchKernelGGL((viterbi_band_split_kernel<H, true>), dim3((unsigned)n_lock), dim3(2 * BP), lds, s, q, t, blt);
             q.split_phase = 4;
@@ -1077,18 +1086,41 @@ hipError_t launch_viterbi_split_spec(const PassParams &p, const DevTables &t, co
     return p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, n_spec, nullptr, -1, s)
                               : launch_split_kernels<50>(p, t, host_lt_band, seg_order, n_spec, nullptr, -1, s);
 }
+// stitch, back-trace, verification, exact walk of the clips `sel` selects (PassParams::clip_sel)
+static void launch_split_finish(const PassParams &p, const DevTables &t, int sel, hipStream_t s) {
+    PassParams q = p;
+    q.clip_sel = sel;
+    hipLaunchKernelGGL(viterbi_segmap_kernel, dim3((unsigned)p.n_seg), dim3(1024), 0, s, q);
+    hipLaunchKernelGGL(viterbi_stitch_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, q);
+    hipLaunchKernelGGL(viterbi_segtrace_kernel, dim3((unsigned)p.n_seg), dim3(256), 0, s, q);
+    hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, s, q, t);
+    hipLaunchKernelGGL(viterbi_exact_kernel, dim3((unsigned)p.n_clips), dim3(64), 0, s, q, t);
+}
 hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
-                                const int32_t *lock_order, int n_lock, hipStream_t s) {
+                                const int32_t *lock_order, int n_lock, hipStream_t s, hipStream_t aux, hipEvent_t *ev) {
     if (p.n_seg == 0) return hipSuccess;
     if (p.split_hybrid) hipLaunchKernelGGL(viterbi_seg0_fill_kernel, dim3((unsigned)p.n_clips), dim3(1024), 0, s, p);
-    hipError_t e = p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, n_spec, lock_order, n_lock, s)
-                                      : launch_split_kernels<50>(p, t, host_lt_band, seg_order, n_spec, lock_order, n_lock, s);
+    // The rounds of second speculation keep ONE workgroup per affected clip busy for a segment's time each while the chip
+    // waits; everything behind the lock-on runs is per clip, so the clips none of whose lock-on runs failed to meet (all
+    // but a few) are stitched, verified and walked on `aux` meanwhile, the others behind their rounds.
+    const bool two = aux != nullptr && ev != nullptr && n_lock > 0 && aux != s;
+    bool forked = false;
+    hipError_t fe = hipSuccess;
+    std::function<void()> fork;
+    if (two) fork = [&]() {
+        fe = hipEventRecord(ev[0], s);
+        if (fe == hipSuccess) fe = hipStreamWaitEvent(aux, ev[0], 0);
+        if (fe != hipSuccess) return;
+        launch_split_finish(p, t, 1, aux);
+        fe = hipEventRecord(ev[1], aux);
+        forked = fe == hipSuccess;
+    };
+    hipError_t e = p.half_width == 25 ? launch_split_kernels<25>(p, t, host_lt_band, seg_order, n_spec, lock_order, n_lock, s, fork)
+                                      : launch_split_kernels<50>(p, t, host_lt_band, seg_order, n_spec, lock_order, n_lock, s, fork);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(viterbi_segmap_kernel, dim3((unsigned)p.n_seg), dim3(1024), 0, s, p);
-    hipLaunchKernelGGL(viterbi_stitch_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, p);
-    hipLaunchKernelGGL(viterbi_segtrace_kernel, dim3((unsigned)p.n_seg), dim3(256), 0, s, p);
-    hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, s, p, t);
-    hipLaunchKernelGGL(viterbi_exact_kernel, dim3((unsigned)p.n_clips), dim3(64), 0, s, p, t);
+    if (fe != hipSuccess) return fe;
+    launch_split_finish(p, t, forked ? 2 : 0, s);
+    if (forked) { fe = hipStreamWaitEvent(s, ev[1], 0); if (fe != hipSuccess) return fe; }
     return hipGetLastError();
 }
 

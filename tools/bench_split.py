@@ -90,6 +90,12 @@ if "ranksh" in which:
     shards = adist.shard_clips(durations, 8)
     for r in range(8):
         run(bench.make_folder_clips(shards[r], durations), f"rank {r} of 8", reps=8, modes=(HYB[0], HYB[1], HYB[2]), kinds=[bench.FOLDER_KINDS[i % 8] for i in shards[r]])
+if "rank8auto" in which:        # rank R of 8 (BENCH_SPLIT_RANKS, default 0 and 4) under the automatic rule only
+    durations = bench.folder_durations(512)
+    shards = adist.shard_clips(durations, 8)
+    for r in (int(x) for x in os.environ.get("BENCH_SPLIT_RANKS", "0,4").split(",")):
+        run(bench.make_folder_clips(shards[r], durations), f"rank {r} of 8", reps=8, modes=(("sequential", "0"), ("automatic (hybrid)", None)),
+            kinds=[bench.FOLDER_KINDS[i % 8] for i in shards[r]])
 if "rank4h" in which:           # a rank of FOUR: 128 ragged clips, un-partitioned streams -- the planner's hybrid-only rule
     durations = bench.folder_durations(512)
     shards = adist.shard_clips(durations, 4)
