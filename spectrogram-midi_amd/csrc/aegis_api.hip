@@ -1002,6 +1002,18 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             }
             cseg0[nc] = n_seg;
             m.seg64 = sf0; m.seg64.insert(m.seg64.end(), sch0.begin(), sch0.end());
+            // vf_off: the frames behind every split clip's first boundary (what the verification kernel's grid covers)
+            {
+                int64_t acc = 0;
+                for (int i = 0; i <= nc; ++i) {
+                    m.seg64.push_back(acc);
+                    if (i < nc && cseg0[i + 1] - cseg0[i] >= 2) {
+                        const int k1 = cseg0[i] + 1;
+                        const int64_t fx = sf0[k1] + sst[k1];            // workspace frame of the first boundary
+                        acc += m.frame_off[i] + frames[pc[i]] - 1 - fx;
+                    }
+                }
+            }
             m.seg32.clear();
             for (auto *v : {&sT, &sst, &sprev, &sclip, &cseg0}) m.seg32.insert(m.seg32.end(), v->begin(), v->end());
             // seg_order: the speculative runs (n_seg entries reserved; a hybrid pass lists only the segments behind the first ones)
@@ -1250,6 +1262,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
             const int64_t *g64 = static_cast<const int64_t *>(w.seg64.p);
             const int32_t *g32 = static_cast<const int32_t *>(w.seg32.p);
             p.seg_f0 = g64; p.seg_ch0 = g64 + n_seg;
+            p.vf_off = g64 + 2 * n_seg; p.vf_total = m.seg64.back();
             p.seg_T = g32; p.seg_store = g32 + n_seg; p.seg_prev = g32 + 2 * n_seg; p.seg_clip = g32 + 3 * n_seg;
             p.clip_seg0 = g32 + 4 * n_seg;
             d_seg_order = g32 + 4 * n_seg + nc + 1; d_lock_order = d_seg_order + n_seg;

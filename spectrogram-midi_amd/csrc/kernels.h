@@ -101,6 +101,8 @@ struct PassParams {
     double *seg_col2;            // [n_seg][2 n_bins] end column of a lock-on run that never met the speculative one (the next round speculates from it)
     int32_t *clip_first;         // [n_clips] the clip's first segment whose lock-on run never met (this round; -1: none)
     int32_t *clip_dirty;         // [n_clips] != 0: a lock-on run of the clip never met (set by the first round): its stitch / verification / exact walk wait for the rounds
+    const int64_t *vf_off;       // [n_clips + 1] prefix of the frames the verification kernel has to look at (a split clip's frames behind its first boundary)
+    int64_t vf_total;            //               = vf_off[n_clips]: its grid covers these, not every frame of the pass
     int32_t clip_sel;            // stitch .. exact walk kernels: 0 every clip, 1 only the clips with clip_dirty == 0, 2 only the others
     int32_t *seg_kg;             // [n_seg] its arg-max
     int32_t *seg_lock;           // [n_seg] local step at which the lock-on run met the speculative run, -1: it did not, -2: it did not and a later round started over from its end column

@@ -538,17 +538,20 @@ __global__ __launch_bounds__(256) void viterbi_verify_kernel(PassParams p, DevTa
     constexpr int CAP = kTubeCap;
     __shared__ int sets[4][2][CAP];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    const int64_t f = (int64_t)blockIdx.x * 4 + w;
-    if (f >= p.n_frames) return;
     const int B = p.n_bins, S = 2 * B, H = p.half_width, W = p.width, NC = p.n_cls;
+    // the wave's frame: the idx-th of the frames behind the clips' first boundaries (vf_off: a hybrid pass has none to verify in
+    // the clips and the steps its sequential kernel decoded -- half the pass -- and a wave per frame that returns at once is not free)
+    const int64_t idx = (int64_t)blockIdx.x * 4 + w;
+    if (idx >= p.vf_total) return;
     int lo = 0, hi = p.n_clips;
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.frame_off[mid] <= f) lo = mid; else hi = mid; }
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (p.vf_off[mid] <= idx) lo = mid; else hi = mid; }
     const int c = lo;
     const int a = p.clip_seg0[c], b = p.clip_seg0[c + 1];
     if (b - a < 2 || !clip_selected(p, c)) return;                // an unsplit clip is the sequential run itself
     const int64_t fc = p.frame_off[c];
     const int64_t fx = p.seg_f0[a + 1] + p.seg_store[a + 1];      // the first boundary: everything up to it is the exact run
-    if (f <= fx) return;
+    const int64_t f = fx + 1 + (idx - p.vf_off[c]);
+    if (f >= p.frame_off[c + 1]) return;
     const int Tc = (int)(p.frame_off[c + 1] - fc), nsp = b - a;
     int why = 0;
     // predecessors of target j at frame fr within thr of the best one, appended to dst (deduplicated)
@@ -1093,7 +1096,7 @@ static void launch_split_finish(const PassParams &p, const DevTables &t, int sel
     hipLaunchKernelGGL(viterbi_segmap_kernel, dim3((unsigned)p.n_seg), dim3(1024), 0, s, q);
     hipLaunchKernelGGL(viterbi_stitch_kernel, dim3((unsigned)((p.n_clips + 63) / 64)), dim3(64), 0, s, q);
     hipLaunchKernelGGL(viterbi_segtrace_kernel, dim3((unsigned)p.n_seg), dim3(256), 0, s, q);
-    hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((p.n_frames + 3) / 4)), dim3(256), 0, s, q, t);
+    if (p.vf_total > 0) hipLaunchKernelGGL(viterbi_verify_kernel, dim3((unsigned)((p.vf_total + 3) / 4)), dim3(256), 0, s, q, t);
     hipLaunchKernelGGL(viterbi_exact_kernel, dim3((unsigned)p.n_clips), dim3(64), 0, s, q, t);
 }
 hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const double *host_lt_band, const int32_t *seg_order, int n_spec,
@@ -1103,7 +1106,8 @@ hipError_t launch_viterbi_split(const PassParams &p, const DevTables &t, const d
     // The rounds of second speculation keep ONE workgroup per affected clip busy for a segment's time each while the chip
     // waits; everything behind the lock-on runs is per clip, so the clips none of whose lock-on runs failed to meet (all
     // but a few) are stitched, verified and walked on `aux` meanwhile, the others behind their rounds.
-    const bool two = aux != nullptr && ev != nullptr && n_lock > 0 && aux != s;
+    // (a handful of clips: the second set of launches costs more than a round hides -- one clip 6.6 -> 6.7 ms with it)
+    const bool two = aux != nullptr && ev != nullptr && n_lock > 0 && aux != s && p.n_clips >= 8;
     bool forked = false;
     hipError_t fe = hipSuccess;
     std::function<void()> fork;
