@@ -504,12 +504,15 @@ def main():
         from spectrogram_midi_amd.engine import AegisEngine
         handle.set_profiling(False)
         # (1) the host-buffer entry aegis_analyze_batch: pageable NumPy arrays in, NumPy arrays out (PCIe both ways)
-        for _ in range(2):                              # the first call sizes the staging buffers
+        dt_host = None
+        for it in range(3):                             # the first call sizes the staging buffers; the faster of the next two
             fence()
             t0 = time.perf_counter()
             handle.analyze_batch(clips, rake_sensitivity=0.6, want_sdb=False)
-            dt_host = time.perf_counter() - t0
+            dt = time.perf_counter() - t0
             fence()
+            if it > 0:
+                dt_host = dt if dt_host is None else min(dt_host, dt)
         dt_host = reduce_max(dt_host)
         host_inclusive = {"ms_per_step": round(dt_host * 1e3, 3), "value": round(total_audio / dt_host, 2),
                           "unit": "audio-seconds/s", "entry": "aegis_analyze_batch (host float32 PCM in, host arrays out, per-clip dicts)"}
