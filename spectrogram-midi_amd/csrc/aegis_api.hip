@@ -894,15 +894,21 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         int64_t hyb_S = 0, hyb_chunk = 0;
         bool hyb_part = false;
         std::vector<int64_t> hyb_cb;
-        if (tsplit && !feed && h->split_hybrid != 0 && (split_auto || h->split_hybrid == 1) && h->n_cus == 256) {
+        if (tsplit && h->split_hybrid != 0 && (split_auto || h->split_hybrid == 1) && h->n_cus == 256) {
             const double step = t.half_width == 25 ? 3.1e-6 : 7.3e-6;
             hyb_part = nc <= h->split_limit && h->split_limit > 0 && h->balanced_chunk > 0 && split_streams(h, nc) != nullptr;
-            const double front = hyb_part ? 0.75 * (double)fp * 43e-9 * (256.0 / 192.0) : 0.8 * (double)fp * 43e-9;
+            double front = hyb_part ? 0.75 * (double)fp * 43e-9 * (256.0 / 192.0) : 0.8 * (double)fp * 43e-9;
+            if (feed) {       // a pass fed from host memory: its frame stage cannot outrun the copies (46.7 GB/s pageable, measured)
+                int64_t samples = 0;
+                for (int i = 0; i < nc; ++i) samples += sample_offsets[pc[i] + 1] - sample_offsets[pc[i]];
+                front = std::max(front, (double)samples * 4.0 / 46.7e9);
+            }
             const int64_t target = (int64_t)((double)h->hybrid_pct / 100.0 * front / (hyb_part ? step : 1.7 * step));
             std::vector<int64_t> bs{0};
             if (hyb_part) {
                 // (one launch of the sequential kernel waiting for a flag per chunk, as in balanced passes: half the chunk size)
-                hyb_chunk = std::max<int64_t>(kViterbiChunk, (h->persistent && sync ? h->balanced_chunk / 2 : h->balanced_chunk) * 64 / nc / kViterbiChunk * kViterbiChunk);
+                // (fed from host memory: the feed's chunk size and a launch per chunk, as balanced passes of that kind take)
+                hyb_chunk = std::max<int64_t>(kViterbiChunk, (feed ? h->feed_chunk : (h->persistent && sync ? h->balanced_chunk / 2 : h->balanced_chunk)) * 64 / nc / kViterbiChunk * kViterbiChunk);
                 for (int64_t b = 1 + std::max<int64_t>(kViterbiChunk, hyb_chunk - kViterbiChunk); b < maxF; b += hyb_chunk) bs.push_back(b);
             } else {
                 int64_t stp = std::max<int64_t>(kViterbiChunk, h->chunk_start / kViterbiChunk * kViterbiChunk);
@@ -912,6 +918,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
                     b += stp;
                 }
             }
+            if (feed && !hyb_part) bs.resize(1);       // (host-fed passes: the partitioned form only)
             size_t best = 0;       // the boundary nearest the target
             for (size_t i = 1; i < bs.size(); ++i)
                 if (std::llabs(bs[i] - 1 - target) < std::llabs(bs[best] - 1 - target)) best = i;
@@ -1205,7 +1212,7 @@ static int analyze_device_locked(aegis_handle *h, const float *d_pcm, const int6
         // Balanced passes launch the Viterbi ONCE: the kernel waits for a flag per time chunk, stored behind the chunk's
         // observation kernel, instead of being launched per chunk (40 launches of 45 us each at 64 clips x 180 s, and the
         // kernel's prologue each time).  It needs the frame stage to run beside it, which the CU partition guarantees.
-        const bool persistent = (may_persist || (hybrid && h->persistent && sync)) && ss != nullptr && nk > 1;
+        const bool persistent = (may_persist || (hybrid && !feed && h->persistent && sync)) && ss != nullptr && nk > 1;
         if (persistent) {
             if (!h->abort_flag.p) {
                 if ((rc = ensure(h, h->abort_flag, 4)) != AEGIS_OK) return rc;

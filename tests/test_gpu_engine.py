@@ -815,10 +815,22 @@ def test_time_split_pass_fed_from_host_memory_chunks_its_frame_stage(sr, monkeyp
     assert h.param("split_flagged_clips") == 0
     again = h.analyze_batch(clips[::-1], want_sdb=False)[::-1]
     h.close()
+    # ... and in the hybrid form (the sequential kernel chunk by chunk behind the copies up to step S, segments behind it)
+    monkeypatch.setenv("AEGIS_SPLIT_HYBRID", "1")
+    monkeypatch.setenv("AEGIS_HYBRID_PCT", "200")
+    monkeypatch.setenv("AEGIS_FEED_CHUNK", "48")               # x 64 / 6 clips = 512-step chunks
+    h = _lib.Handle(sample_rate=sr)
+    hyb = h.analyze_batch(clips + clips[:3], want_sdb=False)   # nine clips
+    S = h.param("last_hybrid_step")
+    assert h.param("last_split_segments") >= 12 and h.param("split_flagged_clips") == 0
+    h.close()
     for r, g, a in zip(ref, got, again):
         for k in r:
             np.testing.assert_array_equal(g[k], r[k], err_msg=k)
             np.testing.assert_array_equal(a[k], r[k], err_msg=k)
+    for r, g in zip(ref + ref[:3], hyb):
+        for k in r:
+            np.testing.assert_array_equal(g[k], r[k], err_msg=f"hybrid {k} S={S}")
 
 
 @pytest.mark.parametrize("persistent", ["1", "0"])
