@@ -94,3 +94,37 @@ def test_folder_mode_two_ranks():
     f_off = np.concatenate([[0], np.cumsum([len(r["f0"]) for r in res])])
     assert line["outputs_check"]["digest"] == bench.outputs_digest(host, f_off, range(6))
     assert line["outputs_check"]["expected"] is None and line["outputs_check"]["match"] is None      # not the 512-clip folder
+
+
+def test_outputs_digest_does_not_depend_on_the_sharding():
+    """bench.outputs_digest (the bench line's `outputs_check`): per-clip CRCs seeded with the clip's folder index, summed --
+    the same number however dist.shard_clips deals the clips to 1, 2, 4 or 8 ranks, different when one frame of one clip
+    changes or two clips swap their outputs."""
+    from spectrogram_midi_amd import dist
+    rng = np.random.default_rng(3)
+    n = 40
+    frames = rng.integers(1, 400, n)
+    per_clip = [{"f0": np.where(rng.random(f) < 0.3, np.nan, rng.uniform(80, 900, f)), "voiced_flag": (rng.random(f) < 0.7).astype(np.uint8),
+                 "rake_mask": (rng.random(f) < 0.1).astype(np.uint8), "rms": rng.random(f).astype(np.float32), "voiced_prob": rng.random(f)}
+                for f in frames]
+
+    def digest(world, clips=per_clip):
+        total = 0
+        for mine in dist.shard_clips(frames.astype(float), world):
+            host = {k: np.concatenate([clips[i][k] for i in mine]) if len(mine) else np.zeros(0) for k in per_clip[0]}
+            off = np.concatenate([[0], np.cumsum([frames[i] for i in mine])]).astype(np.int64)
+            total += bench.outputs_digest(host, off, list(mine))
+        return total
+
+    d1 = digest(1)
+    assert d1 == digest(2) == digest(4) == digest(8) and d1 < 2 ** 53          # (summed over ranks in float64 by bench.py)
+    changed = [dict(c) for c in per_clip]
+    changed[7]["rms"] = changed[7]["rms"].copy()
+    changed[7]["rms"][0] += np.float32(1e-3)
+    assert digest(4, changed) != d1
+    same_len = [i for i in range(n) if frames[i] == frames[0]]
+    swapped = list(per_clip)
+    j = same_len[1] if len(same_len) > 1 else None
+    if j is not None:
+        swapped[0], swapped[j] = swapped[j], swapped[0]
+        assert digest(2, swapped) != d1
