@@ -23,3 +23,17 @@ def test_fixture_shapes():
     assert y.dtype == np.float32 and len(y) == 184014
     assert abs(float(np.max(np.abs(y))) - 0.9) < 1e-6
     assert len(signals.sine_sweep()) == 441000
+
+
+def test_hostile_clips_are_seeded_float32_and_finite():
+    """tools/signals.py::hostile_clips (the GPU parity test on offsets, clipping, impulses, levels around the 1e-6 clamps,
+    out-of-range tones, the Nyquist tone, denormals, a step): same arrays on every call, float32, finite, within [-1, 1]."""
+    import numpy as np
+    from tools import signals
+    a, b = signals.hostile_clips(), signals.hostile_clips()
+    assert len(a) == 15 and list(a) == list(b)
+    for k in a:
+        assert a[k].dtype == np.float32 and a[k].shape == (88200,) and np.isfinite(a[k]).all() and np.abs(a[k]).max() <= 1.0 + 1e-6, k
+        assert np.array_equal(a[k], b[k]), k
+    assert a["denormal"].max() < 1.2e-38 and a["denormal"].min() > 0                 # float32 denormals, not zeros
+    assert np.abs(a["clipped"]).max() == 1.0 and (np.abs(a["clipped"]) == 1.0).mean() > 0.01
