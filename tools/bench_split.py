@@ -80,11 +80,12 @@ if "rank8" in which:
     run(bench.make_folder_clips(mine, durations), "rank 0 of 8: its 64 clips of the 512-clip folder", kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
 HYB = (("sequential", "0"), ("split, frame stage in front", FORCE, {"AEGIS_SPLIT_HYBRID": "0"}), ("hybrid", FORCE)) + tuple(
     (f"hybrid {pct} % / {r} round(s) / min {ms}", FORCE, {"AEGIS_HYBRID_PCT": str(pct), "AEGIS_HYBRID_ROUNDS": str(r), "AEGIS_HYBRID_MIN_SEG": str(ms)})
-    for pct, r, ms in ((100, 3, 768), (100, 4, 512), (100, 5, 512), (100, 6, 384), (108, 4, 512), (92, 4, 512)))
-if "rank8h" in which:           # the hybrid split pass (aegis_api.hip split_hybrid) on rank 0's shard
+    for pct, r, ms in (tuple(int(x) for x in t.split(":")) for t in os.environ.get("BENCH_HYB", "100:3:768,100:4:512,100:5:512,100:6:384,108:4:512,92:4:512").split(",")))
+if "rank8h" in which:           # the hybrid split pass (aegis_api.hip split_hybrid) on a rank's shard (BENCH_SPLIT_RANKS, default 0)
     durations = bench.folder_durations(512)
-    mine = adist.shard_clips(durations, 8)[0]
-    run(bench.make_folder_clips(mine, durations), "rank 0 of 8, hybrid split pass", reps=6, modes=HYB, kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
+    for r in (int(x) for x in os.environ.get("BENCH_SPLIT_RANKS", "0").split(",")):
+        mine = adist.shard_clips(durations, 8)[r]
+        run(bench.make_folder_clips(mine, durations), f"rank {r} of 8, hybrid split pass", reps=6, modes=HYB, kinds=[bench.FOLDER_KINDS[i % 8] for i in mine])
 if "ranksh" in which:
     durations = bench.folder_durations(512)
     shards = adist.shard_clips(durations, 8)
